@@ -1,0 +1,57 @@
+"""Scene builders on top of the *reference's* classes (build container only; TEST INFRA).
+
+Used by the golden generators.  Recipes follow SURVEY.md §8d (config 2: sphere drop,
+config 3: box stack) at sizes that keep fixtures small.
+"""
+import torch
+
+
+def box_stack(nbox=3, seed=0, floor_dims=(4.0, 1.0, 4.0), mu=0.5, rest=0.0, gap=5e-4, requires_grad=True,
+              vel_scale=0.0, push=0.0):
+    from sdf_physics.physics3d.bodies import SDFBox
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+
+    g = torch.Generator().manual_seed(seed)
+    floor = SDFBox([0, -floor_dims[1] / 2, 0], list(floor_dims), custom_mesh=True, custom_inertia=True,
+                   restitution=rest, fric_coeff=mu)
+    bodies, joints, params = [floor], [TotalConstraint3D(floor)], []
+    y = 0.0
+    for _ in range(nbox):
+        dims = 0.9 + 0.2 * torch.rand(3, generator=g, dtype=torch.double)
+        if requires_grad:
+            dims.requires_grad_()
+        off = -0.05 + 0.1 * torch.rand(2, generator=g, dtype=torch.double)
+        yaw = 0.2 * torch.rand(1, generator=g, dtype=torch.double).item()
+        yc = y + gap + dims[1].item() / 2
+        pos = torch.tensor([0, yaw, 0, off[0].item(), yc, off[1].item()], dtype=torch.double)
+        vel = vel_scale * (torch.rand(6, generator=g, dtype=torch.double) - 0.5)
+        vel[4] = -abs(vel[4])  # never start by flying apart
+        vel[3] += push  # lateral shove so that friction saturates (sliding contacts)
+        b = SDFBox(pos, dims, vel=vel, custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+        b.add_force(Gravity3D())
+        y += gap + dims[1].item()
+        bodies.append(b)
+        params.append(dims)
+    return bodies, joints, params
+
+
+def sphere_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), rad=None, y0=None, vx=None, mu=0.25, rest=0.5,
+                requires_grad=True):
+    from sdf_physics.physics3d.bodies import SDFBox, SDFSphere
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+
+    g = torch.Generator().manual_seed(seed)
+    r = 0.4 + 0.2 * torch.rand(1, generator=g, dtype=torch.double)
+    y = 0.7 + 0.5 * torch.rand(1, generator=g, dtype=torch.double)
+    v = torch.rand(1, generator=g, dtype=torch.double)
+    rad_t = torch.tensor(float(r if rad is None else rad), dtype=torch.double, requires_grad=requires_grad)
+    y0 = float(y if y0 is None else y0)
+    vx = float(v if vx is None else vx)
+    floor = SDFBox([0, -floor_dims[1] / 2, 0], list(floor_dims), custom_mesh=True, custom_inertia=True,
+                   restitution=rest, fric_coeff=mu)
+    ball = SDFSphere([0, y0, 0], rad_t, vel=[0, 0, 0, vx, 0, 0], custom_mesh=True, custom_inertia=True,
+                     restitution=rest, fric_coeff=mu)
+    ball.add_force(Gravity3D())
+    return [floor, ball], [TotalConstraint3D(floor)], [rad_t]
