@@ -1,0 +1,82 @@
+"""Loader for the C-ABI HIP library (``include/diffsdfsim_hip.h``).
+
+The product path has NO CPU fallback: if ``libdiffsdfsim_hip.so`` is missing or a tensor is
+not on a HIP device the call raises.  ``build()`` compiles the library in-tree with hipcc
+for gfx950 (cross-compiles without a GPU), so the ``.so`` travels with the source tree.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libdiffsdfsim_hip.so")
+_LIB = None
+
+ABI_VERSION = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/libdiffsdfsim_hip.so (rebuilt when a source is newer)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises HipLibraryError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "%s not found: run `python __graft_entry__.py build` (hipcc, gfx950). "
+                "There is no CPU fallback for the product path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.dss_abi_version.restype = ctypes.c_int
+        if L.dss_abi_version() != ABI_VERSION:
+            raise HipLibraryError("ABI mismatch: library %d, python %d" % (L.dss_abi_version(), ABI_VERSION))
+        L.dss_lcp_dense_workspace_bytes.restype = ctypes.c_size_t
+        _LIB = L
+    return _LIB
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and t.numel() > 0 and not t.is_cuda:
+            raise HipLibraryError("diffsdfsim_amd kernels need tensors on a HIP device (got %s); "
+                                  "there is no CPU fallback" % t.device)
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor as c_void_p (None -> NULL)."""
+    if t is None or t.numel() == 0:
+        return ctypes.c_void_p(0)
+    assert t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipLibraryError("%s failed with code %d" % (what, rc))

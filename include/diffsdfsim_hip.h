@@ -1,0 +1,71 @@
+/*
+ * diffsdfsim_hip.h -- C ABI of libdiffsdfsim_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the hot path of EmbodiedVision/diffsdfsim.  The
+ * reference is pure Python on PyTorch and has no FFI of its own; each entry point below
+ * names the reference *Python* interface it replaces (file:line relative to the reference
+ * root) and INTEGRATION.md shows the ctypes binding a maintainer would add on that side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch allocations);
+ *     nothing is allocated, freed or synchronised inside the library; no global state;
+ *   - double = IEEE binary64 row-major contiguous, int = int32;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call
+ *     returns immediately;
+ *   - return value: 0 = enqueued, negative = argument error (see DSS_E_*).  Numerical
+ *     per-system outcomes are written to the `status` arrays on the device.
+ */
+#ifndef DIFFSDFSIM_HIP_H
+#define DIFFSDFSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSS_ABI_VERSION 1
+
+/* return codes of the launchers */
+#define DSS_OK 0
+#define DSS_E_BADARG (-1)     /* null pointer / non-positive size */
+#define DSS_E_WORKSPACE (-2)  /* workspace smaller than *_workspace_bytes() */
+#define DSS_E_UNSUPPORTED (-3)/* size outside the compiled limits */
+
+/* per-system status words written by the LCP kernels (match the reference's exceptions) */
+#define DSS_LCP_OK 0
+#define DSS_LCP_NOT_SPD 1     /* -> RuntimeError('Q is not SPD.')            lcp.py:109-113  */
+#define DSS_LCP_Q_SINGULAR 2  /* -> RuntimeError("...LU factorization on Q") batch.py:417-424 */
+#define DSS_LCP_INACCURATE 4  /* best residual > 1 (INACC_ERR condition)      batch.py:165-167 */
+
+int dss_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * B1: general dense LCP  --  replaces lcp_physics.lcp.lcp.LCPFunction(...)(Q,p,G,h,A,b,F)
+ *     forward : lcp_physics/lcp/lcp.py:48-153 + lcp_physics/lcp/solvers/batch.py:70-231,413-520
+ *     backward: lcp_physics/lcp/lcp.py:156-213
+ * Shapes: Q[B,nz,nz] p[B,nz] G[B,nineq,nz] h[B,nineq] A[B,neq,nz] b[B,neq] F[B,nineq,nineq].
+ * neq may be 0 (A, b ignored).  Termination tests are applied per system.
+ * ------------------------------------------------------------------------------------ */
+size_t dss_lcp_dense_workspace_bytes(int B, int nz, int nineq, int neq);
+
+int dss_lcp_dense_forward(const double *Q, const double *p, const double *G, const double *h,
+                          const double *A, const double *b, const double *F,
+                          int B, int nz, int nineq, int neq,
+                          double eps, int not_improved_lim, int max_iter, int check_spd,
+                          double *zhat, double *lam, double *slack, double *nu,   /* out */
+                          int *iters, int *status,                                /* out [B] */
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+int dss_lcp_dense_backward(const double *Q, const double *G, const double *A, const double *F,
+                           int B, int nz, int nineq, int neq,
+                           const double *zhat, const double *lam, const double *slack, const double *nu,
+                           const double *dl_dz,
+                           double *dQ, double *dp, double *dG, double *dh, double *dA, double *db, double *dF,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSDFSIM_HIP_H */

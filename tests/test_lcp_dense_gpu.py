@@ -1,0 +1,97 @@
+"""GPU: dense LCP kernel (csrc/lcp_dense.hip) through the C ABI vs reference goldens and the C oracle.
+
+Tolerances: north_star asks 1e-5 relative on velocities / gradients; the kernel follows the
+same elimination as the reference so we hold it to 1e-9 on the (unique) primal solution.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import lcp_goldens, load_lcp, random_lcp, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def run_fwd(g, max_iter, check_spd=True):
+    from diffsdfsim_amd.lcp.lcp import lcp_dense_forward
+    Q, p, G, h, A, b, F = (T(g[k]) for k in "QpGhAbF")
+    out = lcp_dense_forward(Q, p, G, h, A, b, F, 1e-12, 3, max_iter, check_spd)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize("path", lcp_goldens(), ids=lambda p: p.split("/")[-1][:-4])
+def test_forward_matches_reference_golden(path):
+    g = load_lcp(path)
+    z, lam, s, nu, it, st = run_fwd(g, int(g["max_iter"]))
+    assert (st == 0).all(), st
+    assert rel(z, g["zhat"]) < 1e-9
+    assert rel(s, g["slack"]) < 1e-6
+    assert rel(lam, g["lam"]) < 1e-3  # multipliers: see tests/test_oracle_lcp.py
+
+
+@pytest.mark.parametrize("path", lcp_goldens(), ids=lambda p: p.split("/")[-1][:-4])
+def test_backward_matches_reference_golden(path):
+    from diffsdfsim_amd.lcp.lcp import lcp_dense_backward
+    g = load_lcp(path)
+    out = lcp_dense_backward(T(g["Q"]), T(g["G"]), T(g["A"]), T(g["F"]), T(g["zhat"]), T(g["lam"]), T(g["slack"]),
+                             T(g["nu"]), T(g["dl_dz"]))
+    for name, got in zip("QpGhAbF", out):
+        want = g["d" + name]
+        if want.size:
+            assert rel(got.cpu().numpy(), want) < 1e-7, name
+
+
+@pytest.mark.parametrize("shape", [(5, 6, 4, 3), (3, 12, 10, 6), (4, 10, 7, 0), (2, 24, 90, 6), (64, 12, 30, 6), (1, 48, 130, 6)])
+def test_forward_backward_match_oracle_on_fresh_seeds(shape):
+    from oracle import lcp_oracle as O
+    from diffsdfsim_amd.lcp.lcp import lcp_dense_backward
+    nB, nz, nineq, neq = shape
+    Q, p, G, h, A, b, F = random_lcp(1234 + nineq, nB, nz, nineq, neq)
+    g = dict(Q=Q, p=p, G=G, h=h, A=A, b=b, F=F)
+    z, lam, s, nu, it, st = run_fwd(g, 20)
+    zo, lo, so, nuo, ito, sto = O.forward(Q, p, G, h, A, b, F, max_iter=20)
+    assert (st == sto).all()
+    assert (it == ito).all()
+    assert rel(z, zo) < 1e-9 and rel(lam, lo) < 1e-7 and rel(s, so) < 1e-7
+    dl = np.random.default_rng(7).standard_normal((nB, nz))
+    want = O.backward(Q, G, A, F, zo, lo, so, nuo, dl)
+    got = lcp_dense_backward(T(Q), T(G), T(A), T(F), T(zo), T(lo), T(so), T(nuo), T(dl))
+    for name, w, gt in zip("QpGhAbF", want, got):
+        if w.size:
+            assert rel(gt.cpu().numpy(), w) < 1e-8, name
+
+
+def test_lcpfunction_autograd_surface():
+    """Same call surface as lcp_physics.lcp.lcp.LCPFunction: batched + un-batched operands, neq = 0."""
+    from diffsdfsim_amd.lcp import LCPFunction
+    from oracle import lcp_oracle as O
+    Q, p, G, h, A, b, F = random_lcp(5, 3, 6, 4, 0)
+    Qt, pt, Gt, ht, Ft = (T(x).requires_grad_() for x in (Q, p, G, h, F))
+    e = torch.tensor([], device="cuda", dtype=torch.float64)
+    z = LCPFunction(max_iter=10, verbose=-1)(Qt, pt, Gt, ht, e, e, Ft)
+    dl = torch.ones_like(z)
+    z.backward(dl)
+    zo, lo, so, nuo, _, _ = O.forward(Q, p, G, h, np.zeros((3, 0, 6)), np.zeros((3, 0)), F, max_iter=10)
+    assert rel(z.detach().cpu().numpy(), zo) < 1e-9
+    want = O.backward(Q, G, np.zeros((3, 0, 6)), F, zo, lo, so, nuo, np.ones((3, 6)))
+    assert rel(Qt.grad.cpu().numpy(), want[0]) < 1e-7
+    assert rel(Gt.grad.cpu().numpy(), want[2]) < 1e-7
+    # un-batched Q and G broadcast over the batch; their grads are batch means (lcp.py:187-208)
+    Q1 = T(Q[0]).requires_grad_()
+    z2 = LCPFunction(max_iter=10, verbose=-1)(Q1, T(p), T(G), T(h), e, e, T(F))
+    z2.sum().backward()
+    assert Q1.grad.shape == (6, 6)
+
+
+def test_non_spd_raises_like_reference():
+    from diffsdfsim_amd.lcp import LCPFunction
+    Q = -torch.eye(4, dtype=torch.float64, device="cuda")[None]
+    e = torch.tensor([], device="cuda", dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="Q is not SPD"):
+        LCPFunction()(Q, torch.zeros(1, 4, device="cuda").double(), torch.ones(1, 2, 4, device="cuda").double(),
+                      torch.ones(1, 2, device="cuda").double(), e, e, torch.zeros(1, 2, 2, device="cuda").double())
