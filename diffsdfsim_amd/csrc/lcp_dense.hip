@@ -12,7 +12,7 @@
 // (L2 / Infinity-Cache resident for the sizes of SURVEY.md §8: <= 2.6 MB per system),
 // nz- and neq-sized vectors and the Schur right-hand side are staged in LDS, rows are
 // walked with lane = column so every global access is a coalesced 512-B row segment.
-#include <hip/hip_runtime.h>
+#include "dss_device.h"
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"
@@ -396,7 +396,7 @@ lcp_dense_forward_kernel(const double *Q, const double *p, const double *G, cons
                          int not_improved_lim, int max_iter, int check_spd, double *zhat, double *lam,
                          double *slack, double *nu, int *iters, int *status, char *workspace, size_t ws_stride)
 {
-    extern __shared__ __align__(16) double lds[];
+    DSS_DYN_LDS(double, lds);
     const int sys = blockIdx.x, lane = lane_id();
     Sys S;
     S.nz = nz; S.nineq = nineq; S.neq = neq;
@@ -506,7 +506,7 @@ lcp_dense_backward_kernel(const double *Q, const double *G, const double *A, con
                           const double *dl_dz, double *dQ, double *dp, double *dG, double *dh, double *dA,
                           double *db, double *dF, char *workspace, size_t ws_stride)
 {
-    extern __shared__ __align__(16) double lds[];
+    DSS_DYN_LDS(double, lds);
     const int sys = blockIdx.x, lane = lane_id();
     Sys S;
     S.nz = nz; S.nineq = nineq; S.neq = neq;

@@ -1,6 +1,6 @@
 // wave_utils.h -- 64-lane wavefront helpers shared by the gfx950 kernels.
 #pragma once
-#include <hip/hip_runtime.h>
+#include "dss_device.h"
 
 namespace dss {
 

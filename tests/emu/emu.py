@@ -1,0 +1,59 @@
+"""ctypes front end of the CPU emulation build of the kernels (TEST INFRASTRUCTURE ONLY)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    if _LIB is None:
+        _LIB = ctypes.CDLL(os.path.join(_HERE, "_build", "libdss_emu.so"))
+        _LIB.dss_lcp_dense_workspace_bytes.restype = ctypes.c_size_t
+    return _LIB
+
+
+import numpy as np  # noqa: E402
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None and a.size else ctypes.c_void_p(0)
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def lcp_dense_forward(Q, p, G, h, A, b, F, eps=1e-12, nil=3, max_iter=20, check_spd=True):
+    L = lib()
+    Q, p, G, h, A, b, F = (_c(x) for x in (Q, p, G, h, A, b, F))
+    B, nineq, nz = G.shape
+    neq = A.shape[1] if A.size else 0
+    zhat = np.zeros((B, nz)); lam = np.zeros((B, nineq)); slack = np.zeros((B, nineq)); nu = np.zeros((B, neq))
+    iters = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
+    nbytes = L.dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)
+    ws = np.zeros(nbytes, np.uint8)
+    rc = L.dss_lcp_dense_forward(_p(Q), _p(p), _p(G), _p(h), _p(A), _p(b), _p(F), B, nz, nineq, neq,
+                                 ctypes.c_double(eps), nil, max_iter, int(check_spd), _p(zhat), _p(lam), _p(slack),
+                                 _p(nu), _p(iters), _p(status), _p(ws), ctypes.c_size_t(nbytes), None)
+    assert rc == 0, rc
+    return zhat, lam, slack, nu, iters, status
+
+
+def lcp_dense_backward(Q, G, A, F, zhat, lam, slack, nu, dl):
+    L = lib()
+    Q, G, A, F, zhat, lam, slack, nu, dl = (_c(x) for x in (Q, G, A, F, zhat, lam, slack, nu, dl))
+    B, nineq, nz = G.shape
+    neq = A.shape[1] if A.size else 0
+    mk = lambda *s: np.zeros(s)
+    dQ, dp, dG, dh, dA, db, dF = mk(B, nz, nz), mk(B, nz), mk(B, nineq, nz), mk(B, nineq), mk(B, neq, nz), mk(B, neq), mk(B, nineq, nineq)
+    nbytes = L.dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)
+    ws = np.zeros(nbytes, np.uint8)
+    rc = L.dss_lcp_dense_backward(_p(Q), _p(G), _p(A), _p(F), B, nz, nineq, neq, _p(zhat), _p(lam), _p(slack), _p(nu),
+                                  _p(dl), _p(dQ), _p(dp), _p(dG), _p(dh), _p(dA), _p(db), _p(dF), _p(ws),
+                                  ctypes.c_size_t(nbytes), None)
+    assert rc == 0, rc
+    return dQ, dp, dG, dh, dA, db, dF

@@ -1,0 +1,148 @@
+// hip_emu.h -- TEST-ONLY functional emulation of the small HIP device subset our kernels use.
+//
+// The build container has no GPU.  To debug kernel *logic* on the CPU, tests/emu compiles the
+// very same .hip sources with g++ -DDSS_EMU against this header: every thread of a block is a
+// ucontext fiber, fibers run round-robin and switch at __syncthreads()/__shfl*, which gives the
+// lock-step semantics a 64-lane wavefront has.  Nothing here is linked into, or reachable from,
+// the product library (diffsdfsim_amd/csrc/libdiffsdfsim_hip.so); see tests/emu/README.md.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __align__(n)
+#define __restrict__
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+constexpr int hipSuccess = 0;
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
+namespace dss_emu {
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    bool done = false;
+};
+struct State {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    int cur = 0;
+    std::vector<char> dyn_lds;
+    std::vector<uint64_t> slots;
+    std::function<void()> body;
+};
+inline State &st() { static State s; return s; }
+inline emu_uint3 &tidx() { static emu_uint3 v; return v; }
+inline emu_uint3 &bidx() { static emu_uint3 v; return v; }
+inline dim3 &bdim() { static dim3 v; return v; }
+inline dim3 &gdim() { static dim3 v; return v; }
+
+inline void yield()
+{
+    State &s = st();
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+inline void trampoline()
+{
+    State &s = st();
+    s.body();
+    s.fibers[s.cur].done = true;
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+inline void run_block(unsigned nthreads)
+{
+    State &s = st();
+    s.fibers.clear();
+    s.fibers.resize(nthreads);
+    s.slots.assign(nthreads, 0);
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber &f = s.fibers[t];
+        f.stack.resize(256 * 1024);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = &s.sched;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    bool alive = true;
+    while (alive) {
+        alive = false;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            if (s.fibers[t].done) continue;
+            s.cur = (int)t;
+            tidx().x = t;
+            swapcontext(&s.sched, &s.fibers[t].ctx);
+            alive = true;
+        }
+    }
+}
+template <class F> inline void launch(dim3 grid, dim3 block, size_t lds_bytes, F &&f)
+{
+    State &s = st();
+    gdim() = grid;
+    bdim() = block;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        bidx().x = b; bidx().y = 0; bidx().z = 0;
+        s.dyn_lds.assign(lds_bytes + 64, 0);
+        s.body = f;
+        run_block(block.x);
+    }
+}
+template <class T> inline T shfl_from(T v, int src)
+{
+    static_assert(sizeof(T) <= 8, "emu shuffle width");
+    State &s = st();
+    uint64_t raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    s.slots[s.cur] = raw;
+    yield();
+    int wave_base = (s.cur / 64) * 64;
+    uint64_t got = s.slots[wave_base + (src & 63)];
+    yield();
+    T out;
+    std::memcpy(&out, &got, sizeof(T));
+    return out;
+}
+}  // namespace dss_emu
+
+#define threadIdx (dss_emu::tidx())
+#define blockIdx (dss_emu::bidx())
+#define blockDim (dss_emu::bdim())
+#define gridDim (dss_emu::gdim())
+
+inline void __syncthreads() { dss_emu::yield(); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return dss_emu::shfl_from(v, (dss_emu::st().cur & 63) ^ mask); }
+template <class T> inline T __shfl(T v, int src, int = 64) { return dss_emu::shfl_from(v, src); }
+template <class T> inline T __shfl_down(T v, int d, int = 64)
+{
+    int l = dss_emu::st().cur & 63;
+    return dss_emu::shfl_from(v, l + d < 64 ? l + d : l);
+}
+inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
+inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    dss_emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+
+// dynamic LDS: the kernels declare it through DSS_DYN_LDS(type, name)
+#define DSS_DYN_LDS(type, name) type *name = reinterpret_cast<type *>(dss_emu::st().dyn_lds.data())

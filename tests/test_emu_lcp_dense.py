@@ -1,0 +1,32 @@
+"""CPU: kernel LOGIC of csrc/lcp_dense.hip run through the fiber emulator (tests/emu) vs goldens/oracle.
+
+This is not the product path and proves nothing about the GPU build; the parity tests proper are
+tests/test_lcp_dense_gpu.py.  It lets the CPU-only container catch indexing / algorithm errors.
+"""
+import numpy as np
+import pytest
+
+from helpers import lcp_goldens, load_lcp, random_lcp, rel
+from emu import emu
+
+SMALL = [p for p in lcp_goldens() if "stack3" not in p and "stack1" not in p]
+
+
+@pytest.mark.parametrize("path", SMALL, ids=lambda p: p.split("/")[-1][:-4])
+def test_emulated_kernel_matches_reference_golden(path):
+    g = load_lcp(path)
+    z, lam, s, nu, it, st = emu.lcp_dense_forward(g["Q"], g["p"], g["G"], g["h"], g["A"], g["b"], g["F"], max_iter=int(g["max_iter"]))
+    assert (st == 0).all()
+    assert rel(z, g["zhat"]) < 1e-9
+    out = emu.lcp_dense_backward(g["Q"], g["G"], g["A"], g["F"], g["zhat"], g["lam"], g["slack"], g["nu"], g["dl_dz"])
+    for name, got in zip("QpGhAbF", out):
+        if g["d" + name].size:
+            assert rel(got, g["d" + name]) < 1e-7, name
+
+
+def test_emulated_kernel_matches_oracle_random():
+    from oracle import lcp_oracle as O
+    Q, p, G, h, A, b, F = random_lcp(3, 2, 8, 9, 2)
+    z, lam, s, nu, it, st = emu.lcp_dense_forward(Q, p, G, h, A, b, F)
+    zo, lo, so, nuo, ito, sto = O.forward(Q, p, G, h, A, b, F)
+    assert (it == ito).all() and rel(z, zo) < 1e-10
