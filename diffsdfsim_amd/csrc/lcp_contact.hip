@@ -1,0 +1,829 @@
+// lcp_contact.hip -- contact-structured frictional LCP for gfx950: one wavefront per scene,
+// the whole KKT factor/solve in LDS.
+//
+// Solves exactly the mixed LCP the reference's PdipmEngine assembles (engines.py:56-81) with the
+// same predictor-corrector iteration as the reference solver (batch.py:70-231), but never builds
+// the dense G [nineq x nz] and F [nineq x nineq]:
+//
+//   * every inequality row of a contact c between bodies (b1,b2) is  +-[p1 x D, D | -p2 x D, -D]
+//     for a direction D in {n, d_1..d_ND} (physics3d/world.py:56-101), i.e. row = (P_c D)^T with
+//     P_c = [X(p1); I; -X(p2); -I] (12x3);
+//   * F couples only the (2 ND + 2) rows of one contact (engines.py:72-78), so (F + diag(s/z)) is
+//     block diagonal with an arrow-shaped block per contact that is inverted in closed form.
+//
+// Eliminating ds and dz contact by contact (instead of the reference's dual-side Schur complement
+// T = R + D^-1 of size nineq, batch.py:485-520) leaves the reduced system
+//        [ Q + sum_c P_c C_c P_c^T   A^T ] [dx]   [rhs_x]
+//        [ A                          0  ] [dy] = [rhs_y]          (n = nz + neq <= 64)
+// with a 3x3 matrix C_c per contact.  The two are the same Newton system, so the iterates agree
+// with the reference to rounding (verified against its goldens: 1e-13 on the velocities).
+//
+// Mapping: blockDim = 64 (one wave) per scene.  LDS: K (n x n, odd leading dimension => conflict
+// free column walks), contact points, per-contact 3-vectors / C matrices, nz-sized vectors.
+// Per-contact IPM state (s, z, rz, ds, dz: NR doubles each) streams through an L2-resident
+// workspace in [row][contact] order so lane = contact loads are coalesced.  All cross-contact
+// sums are ordered (per-body contact lists, sequential K accumulation): results are bitwise
+// reproducible run to run.
+#include <math.h>
+
+#include "../../include/diffsdfsim_hip.h"
+#include "wave_utils.h"
+
+namespace {
+using namespace dss;
+
+template <int ND> struct Geo {
+    static constexpr int NR = 2 * ND + 2;       // rows per contact: normal, ND +dirs, ND -dirs, cone
+    static constexpr int NF = 3 * (1 + ND) + 8; // operand fields per contact
+    double D[1 + ND][3];
+    double p1[3], p2[3], mu, hn;
+    int b1, b2;
+};
+
+template <int ND> __device__ inline void load_geo(Geo<ND> &g, const double *cop, const int *cbody, int maxc, int c)
+{
+#pragma unroll
+    for (int k = 0; k < 1 + ND; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g.D[k][j] = cop[(size_t)(3 * k + j) * maxc + c];
+    const int o = 3 * (1 + ND);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { g.p1[j] = cop[(size_t)(o + j) * maxc + c]; g.p2[j] = cop[(size_t)(o + 3 + j) * maxc + c]; }
+    g.mu = cop[(size_t)(o + 6) * maxc + c];
+    g.hn = cop[(size_t)(o + 7) * maxc + c];
+    g.b1 = cbody[c];
+    g.b2 = cbody[maxc + c];
+}
+
+__device__ inline void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// relative velocity functional of a generalized vector v (LDS, [w(3), u(3)] per body):
+//   vr = (w1 x p1 + u1) - (w2 x p2 + u2);   (G v)_row = +-D . vr
+template <int ND> __device__ inline void rel_vel(const double *v, const Geo<ND> &g, double *vr)
+{
+    const double *a = v + 6 * g.b1, *b = v + 6 * g.b2;
+    double t1[3], t2[3];
+    cross3(a, g.p1, t1);
+    cross3(b, g.p2, t2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vr[j] = (t1[j] + a[3 + j]) - (t2[j] + b[3 + j]);
+}
+template <int ND> __device__ inline void g_rows(const Geo<ND> &g, const double *vr, double *gx)
+{
+    gx[0] = dot3(g.D[0], vr);
+#pragma unroll
+    for (int k = 1; k <= ND; ++k) { double t = dot3(g.D[k], vr); gx[k] = t; gx[ND + k] = -t; }
+    gx[2 * ND + 1] = 0.0;
+}
+// (F z) of one contact, engines.py:72-78
+template <int ND> __device__ inline void f_rows(double mu, const double *z, double *fz)
+{
+    double sum = 0.0;
+    fz[0] = 0.0;
+#pragma unroll
+    for (int k = 1; k <= 2 * ND; ++k) { fz[k] = z[2 * ND + 1]; sum += z[k]; }
+    fz[2 * ND + 1] = mu * z[0] - sum;
+}
+// u = (F_c + diag(a))^-1 r   (arrow block, closed form)
+template <int ND> __device__ inline void w_apply(double mu, const double *a, const double *r, double *u)
+{
+    double den = a[2 * ND + 1], num = r[2 * ND + 1] - mu * r[0] / a[0];
+#pragma unroll
+    for (int k = 1; k <= 2 * ND; ++k) { den += 1.0 / a[k]; num += r[k] / a[k]; }
+    const double ug = num / den;
+    u[0] = r[0] / a[0];
+#pragma unroll
+    for (int k = 1; k <= 2 * ND; ++k) u[k] = (r[k] - ug) / a[k];
+    u[2 * ND + 1] = ug;
+}
+// w = sum_rows sign_r u_r D_r  ( G_c^T u = P_c w )
+template <int ND> __device__ inline void w_vec(const Geo<ND> &g, const double *u, double *w)
+{
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double acc = u[0] * g.D[0][j];
+#pragma unroll
+        for (int k = 1; k <= ND; ++k) acc += (u[k] - u[ND + k]) * g.D[k][j];
+        w[j] = acc;
+    }
+}
+// C_c with G_c^T (F_c + diag(a))^-1 G_c = P_c C_c P_c^T
+template <int ND> __device__ inline void c_mat(const Geo<ND> &g, const double *a, double *C)
+{
+    double den = a[2 * ND + 1], bv[3] = {0, 0, 0};
+    const double ian = 1.0 / a[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = ian * g.D[0][i] * g.D[0][j];
+#pragma unroll
+    for (int k = 1; k <= ND; ++k) {
+        const double i1 = 1.0 / a[k], i2 = 1.0 / a[ND + k];
+        den += i1 + i2;
+        const double al = i1 + i2, be = i1 - i2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bv[i] += be * g.D[k][i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) C[3 * i + j] += al * g.D[k][i] * g.D[k][j];
+        }
+    }
+    const double iden = 1.0 / den;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] -= bv[i] * (bv[j] - g.mu * ian * g.D[0][j]) * iden;
+}
+
+// ---- LDS-resident state of one scene ------------------------------------------------------
+struct Lds {
+    double *K;      // n x lda
+    double *pbuf;   // [maxc][6]  p1, p2
+    double *cw;     // [maxc][9]  C matrices  /  [maxc][6] two 3-vector payloads
+    double *xv;     // [n] current (x, y)
+    double *g1, *g2;// [nz] gathered G^T products
+    double *sol;    // [n] latest solve result
+    double *dxa;    // [n] affine direction
+    double *pl;     // [nz] linear term
+    int *piv;       // [n]
+    int *bl_start;  // [nb+1]
+    int *bl_ent;    // [2*maxc]  contact*2 + side
+    int n, lda, nz, neq, nb, maxc;
+};
+
+__host__ __device__ inline size_t lds_doubles(int nb, int neq, int maxc)
+{
+    const int nz = 6 * nb, n = nz + neq, lda = n | 1;
+    return (size_t)n * lda + 6 * (size_t)maxc + 9 * (size_t)maxc + 3 * (size_t)n + 3 * (size_t)nz + 4;
+}
+__host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
+{
+    const int n = 6 * nb + neq;
+    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 2 * maxc + 4) * 4;
+}
+__device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc)
+{
+    L.nb = nb; L.neq = neq; L.maxc = maxc; L.nz = 6 * nb; L.n = L.nz + neq; L.lda = L.n | 1;
+    double *q = base;
+    L.K = q; q += (size_t)L.n * L.lda;
+    L.pbuf = q; q += 6 * maxc;
+    L.cw = q; q += 9 * maxc;
+    L.xv = q; q += L.n;
+    L.sol = q; q += L.n;
+    L.dxa = q; q += L.n;
+    L.g1 = q; q += L.nz;
+    L.g2 = q; q += L.nz;
+    L.pl = q; q += L.nz;
+    q += 4;
+    int *ip = reinterpret_cast<int *>(q);
+    L.piv = ip; ip += L.n;
+    L.bl_start = ip; ip += nb + 1;
+    L.bl_ent = ip;
+}
+
+// per-body contact lists in ascending contact order (deterministic gathers)
+__device__ void build_lists(Lds &L, const int *cbody, int nc)
+{
+    const int lane = lane_id();
+    if (lane < L.nb) {
+        int cnt = 0;
+        for (int c = 0; c < nc; ++c) cnt += (cbody[c] == lane) + (cbody[L.maxc + c] == lane);
+        L.bl_start[lane + 1] = cnt;
+    }
+    if (lane == 0) L.bl_start[0] = 0;
+    __syncthreads();
+    if (lane == 0)
+        for (int b = 0; b < L.nb; ++b) L.bl_start[b + 1] += L.bl_start[b];
+    __syncthreads();
+    if (lane < L.nb) {
+        int o = L.bl_start[lane];
+        for (int c = 0; c < nc; ++c) {
+            if (cbody[c] == lane) L.bl_ent[o++] = 2 * c;
+            if (cbody[L.maxc + c] == lane) L.bl_ent[o++] = 2 * c + 1;
+        }
+    }
+    __syncthreads();
+}
+
+// out[6b..6b+5] = sum over contacts of body b of  +-[p x w, w]   (NP payloads of 3 doubles in L.cw)
+template <int NP> __device__ void gather(const Lds &L, double *out0, double *out1)
+{
+    const int lane = lane_id();
+    if (lane < L.nb) {
+        double acc[NP][6];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[q][j] = 0.0;
+        for (int e = L.bl_start[lane]; e < L.bl_start[lane + 1]; ++e) {
+            const int ent = L.bl_ent[e], c = ent >> 1, side = ent & 1;
+            const double *p = L.pbuf + 6 * c + 3 * side;
+            const double sg = side ? -1.0 : 1.0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const double *w = L.cw + (size_t)(3 * NP) * c + 3 * q;
+                double t[3];
+                cross3(p, w, t);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { acc[q][j] += sg * t[j]; acc[q][3 + j] += sg * w[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            out0[6 * lane + j] = acc[0][j];
+            if (NP > 1) out1[6 * lane + j] = acc[NP - 1][j];
+        }
+    }
+    __syncthreads();
+}
+
+// K = [[Q + sum_c P C P^T, A^T],[A, 0]]  (C matrices in L.cw, 9 per contact)
+__device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const int *cbody, int nc)
+{
+    const int lane = lane_id(), n = L.n, lda = L.lda, nz = L.nz;
+    for (int e = lane; e < n * lda; e += WAVE) L.K[e] = 0.0;
+    __syncthreads();
+    for (int e = lane; e < L.nb * 36; e += WAVE) {
+        const int b = e / 36, i = (e % 36) / 6, j = e % 6;
+        L.K[(6 * b + i) * lda + 6 * b + j] = Mblk[e];
+    }
+    for (int e = lane; e < L.neq * nz; e += WAVE) {
+        const int i = e / nz, j = e % nz;
+        const double v = A[e];
+        L.K[(nz + i) * lda + j] = v;
+        L.K[j * lda + nz + i] = v;
+    }
+    __syncthreads();
+    // lanes 0..47: (row r of the 12 local rows) x (4 column groups of 3)
+    const int r = lane >> 2, grp = lane & 3;
+    const int br = r / 6, rr = r % 6, bc = grp >> 1, kind = grp & 1;
+    const double sgn = (br == bc) ? 1.0 : -1.0;
+    if (lane < 48)
+        for (int c = 0; c < nc; ++c) {
+            const double *C = L.cw + 9 * c;
+            const double *pr = L.pbuf + 6 * c + 3 * br, *pc = L.pbuf + 6 * c + 3 * bc;
+            double a[3], o[3];
+            if (rr < 3) {  // row rr of X(p) C : (p x C[:,j])[rr]
+                const int i1 = (rr + 1) % 3, i2 = (rr + 2) % 3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[j] = pr[i1] * C[3 * i2 + j] - pr[i2] * C[3 * i1 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[j] = C[3 * (rr - 3) + j];
+            }
+            if (kind == 0) cross3(pc, a, o);
+            else { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+            const int row = 6 * cbody[br * L.maxc + c] + rr, col = 6 * cbody[bc * L.maxc + c] + 3 * kind;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.K[row * lda + col + j] += sgn * o[j];
+        }
+    __syncthreads();
+}
+
+// In-place partial-pivot LU of K (n <= 64) in LDS.
+__device__ void factor_K(Lds &L)
+{
+    const int lane = lane_id(), n = L.n, lda = L.lda;
+    double *K = L.K;
+    for (int k = 0; k < n; ++k) {
+        double v = (lane >= k && lane < n) ? fabs(K[lane * lda + k]) : -1.0;
+        int p = lane;
+        wave_argmax(v, p);
+        if (lane == 0) L.piv[k] = p;
+        if (p != k && lane < n) {
+            const double t = K[k * lda + lane];
+            K[k * lda + lane] = K[p * lda + lane];
+            K[p * lda + lane] = t;
+        }
+        __syncthreads();
+        const double inv = 1.0 / K[k * lda + k];
+        if (lane > k && lane < n) K[lane * lda + k] *= inv;
+        __syncthreads();
+        const int m = n - k - 1;
+        if (m > 0) {
+            // 2-D lane map: w lanes across a row, 64/w rows per pass
+            const int w = m > 32 ? 64 : (m > 16 ? 32 : (m > 8 ? 16 : 8));
+            const int rpp = 64 / w, lr = lane / w, lc = lane % w;
+            for (int i0 = 0; i0 < m; i0 += rpp) {
+                const int i = k + 1 + i0 + lr, j = k + 1 + lc;
+                if (i < n && j < n) K[i * lda + j] -= K[i * lda + k] * K[k * lda + j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Solve K x = rhs with rhs/x distributed one entry per lane (lane i <-> entry i).
+__device__ double solve_K(const Lds &L, double x)
+{
+    const int lane = lane_id(), n = L.n, lda = L.lda;
+    const double *K = L.K;
+    for (int k = 0; k < n; ++k) {
+        const int p = L.piv[k];
+        const double xk = __shfl(x, k, WAVE), xp = __shfl(x, p, WAVE);
+        if (p != k) { if (lane == k) x = xp; else if (lane == p) x = xk; }
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        const double xk = __shfl(x, k, WAVE);
+        if (lane > k && lane < n) x -= K[lane * lda + k] * xk;
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        if (lane == k) x /= K[k * lda + k];
+        const double xk = __shfl(x, k, WAVE);
+        if (lane < k) x -= K[lane * lda + k] * xk;
+    }
+    return x;
+}
+
+// (Q v)_i for the block-diagonal Q
+__device__ inline double q_times(const double *Mblk, const double *v, int i)
+{
+    const int b = i / 6, r = i % 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc += Mblk[36 * b + 6 * r + j] * v[6 * b + j];
+    return acc;
+}
+
+// reference get_step (batch.py:234-237) pieces accumulated per lane
+struct StepAcc {
+    double amax = -INFINITY, amin_keep = INFINITY;
+    int any_pos = 0;
+    __device__ inline void add(double v, double dv)
+    {
+        const double a = -v / dv;
+        amax = fmax(amax, a);
+        if (dv > 0.0) any_pos = 1; else amin_keep = fmin(amin_keep, a);
+    }
+    __device__ inline double finish()
+    {
+        const double mx = wave_max(amax), mn = wave_min(amin_keep);
+        const double anyp = wave_max((double)any_pos);
+        const double repl = mx > 1.0 ? mx : 1.0;
+        return anyp > 0.0 ? fmin(mn, repl) : mn;
+    }
+};
+
+template <int ND>
+__global__ void __launch_bounds__(64)
+lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const double *A_, const double *bvec_,
+                           const double *cop_, const int *cbody_, const int *ncs, int nb, int neq, int maxc,
+                           double eps, int not_improved_lim, int max_iter, double *x_out_, double *lam_,
+                           double *slack_, double *nu_, int *iters, int *status, double *ws_)
+{
+    constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
+    DSS_DYN_LDS(double, ldsmem);
+    const int sc = blockIdx.x, lane = lane_id();
+    Lds L;
+    carve_lds(L, ldsmem, nb, neq, maxc);
+    const int nz = L.nz, n = L.n;
+    const double *Mblk = Mblk_ + (size_t)sc * nb * 36, *pvec = pvec_ + (size_t)sc * nz;
+    const double *A = neq ? A_ + (size_t)sc * neq * nz : nullptr, *bvec = neq ? bvec_ + (size_t)sc * neq : nullptr;
+    const double *cop = cop_ + (size_t)sc * NF * maxc;
+    const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
+    double *x_out = x_out_ + (size_t)sc * nz, *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
+    double *nu = neq ? nu_ + (size_t)sc * neq : nullptr;
+    double *ws = ws_ + (size_t)sc * 5 * NR * maxc;
+    double *cs = ws, *cz = ws + (size_t)NR * maxc, *crz = ws + (size_t)2 * NR * maxc, *cds = ws + (size_t)3 * NR * maxc,
+           *cdz = ws + (size_t)4 * NR * maxc;
+    int nc = ncs[sc];
+    if (nc > maxc) nc = maxc;
+    const int nineq = nc * NR;
+
+    for (int i = lane; i < nz; i += WAVE) L.pl[i] = pvec[i];
+    for (int c = lane; c < nc; c += WAVE) {
+        const int o = 3 * (1 + ND);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) L.pbuf[6 * c + j] = cop[(size_t)(o + j) * maxc + c];
+    }
+    __syncthreads();
+    build_lists(L, cbody, nc);
+
+    // ---- initial point: d = 1  (batch.py:85-110) -------------------------------------------
+    for (int c = lane; c < nc; c += WAVE) {
+        Geo<ND> g;
+        load_geo<ND>(g, cop, cbody, maxc, c);
+        double a[NR], t[NR], u[NR], w[3], C[9];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { a[r] = 1.0; t[r] = 0.0; }
+        t[0] = -g.hn;  // rz - rs/d with rz = -h, rs = 0
+        w_apply<ND>(g.mu, a, t, u);
+        w_vec<ND>(g, u, w);
+        c_mat<ND>(g, a, C);
+        // the C matrices go to K first; stash w in the (not yet used) ds scratch
+#pragma unroll
+        for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cds[(size_t)j * maxc + c] = w[j];
+    }
+    __syncthreads();
+    assemble_K(L, Mblk, A, cbody, nc);
+    factor_K(L);
+    for (int c = lane; c < nc; c += WAVE)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = cds[(size_t)j * maxc + c];
+    __syncthreads();
+    gather<1>(L, L.g1, nullptr);
+    {
+        double rhs = 0.0;
+        if (lane < nz) rhs = -L.pl[lane] - L.g1[lane];
+        else if (lane < n) rhs = bvec[lane - nz];
+        const double sol = solve_K(L, rhs);
+        if (lane < n) L.xv[lane] = sol;
+    }
+    __syncthreads();
+    if (nc == 0) {  // no complementarity conditions: the linear solve is the answer (engines.py:40-54)
+        if (lane < nz) x_out[lane] = L.xv[lane];
+        else if (lane < n) nu[lane - nz] = L.xv[lane];
+        if (lane == 0) { iters[sc] = 0; status[sc] = DSS_LCP_OK; }
+        return;
+    }
+    {
+        double mins = INFINITY, minz = INFINITY;
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double a[NR], r[NR], u[NR], vr[3];
+            rel_vel<ND>(L.xv, g, vr);
+            g_rows<ND>(g, vr, r);
+            r[0] -= g.hn;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) a[q] = 1.0;
+            w_apply<ND>(g.mu, a, r, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                cz[(size_t)q * maxc + c] = u[q];
+                cs[(size_t)q * maxc + c] = -u[q];
+                minz = fmin(minz, u[q]);
+                mins = fmin(mins, -u[q]);
+            }
+        }
+        mins = wave_min(mins);
+        minz = wave_min(minz);
+        __syncthreads();
+        for (int c = lane; c < nc; c += WAVE)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                if (mins < 0) cs[(size_t)q * maxc + c] -= mins - 1.0;
+                if (minz < 0) cz[(size_t)q * maxc + c] -= minz - 1.0;
+            }
+        __syncthreads();
+    }
+
+    double best = 0.0;
+    int have_best = 0, not_improved = 0, it = 0;
+    for (it = 0; it < max_iter; ++it) {
+        // ---- residuals (batch.py:117-131) and the affine right-hand side ---------------------
+        double acc_rz = 0.0, acc_sz = 0.0;
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double s[NR], z[NR], gx[NR], fz[NR], a[NR], t[NR], u[NR], vr[3], w[3];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { s[q] = cs[(size_t)q * maxc + c]; z[q] = cz[(size_t)q * maxc + c]; }
+            rel_vel<ND>(L.xv, g, vr);
+            g_rows<ND>(g, vr, gx);
+            f_rows<ND>(g.mu, z, fz);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double rz = gx[q] + s[q] - (q == 0 ? g.hn : 0.0) - fz[q];
+                crz[(size_t)q * maxc + c] = rz;
+                acc_rz += rz * rz;
+                acc_sz += s[q] * z[q];
+                a[q] = s[q] / z[q];
+                t[q] = rz - s[q];  // rz - rs/d with rs = z
+            }
+            w_vec<ND>(g, z, w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[6 * c + j] = w[j];
+            w_apply<ND>(g.mu, a, t, u);
+            w_vec<ND>(g, u, w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[6 * c + 3 + j] = w[j];
+        }
+        acc_rz = wave_sum(acc_rz);
+        const double sz = wave_sum(acc_sz);
+        __syncthreads();
+        gather<2>(L, L.g1, L.g2);  // g1 = G^T z, g2 = G^T W (rz - s)
+        double rx = 0.0, ry = 0.0;
+        if (lane < nz) {
+            rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane];
+            for (int e = 0; e < neq; ++e) rx += A[e * nz + lane] * L.xv[nz + e];
+        } else if (lane < n) {
+            const int e = lane - nz;
+            for (int j = 0; j < nz; ++j) ry += A[e * nz + j] * L.xv[j];
+            ry -= bvec[e];
+        }
+        const double nrx = sqrt(wave_sum(rx * rx)), nry = sqrt(wave_sum(ry * ry));
+        const double mu = fabs(sz / nineq);
+        const double resid = sqrt(acc_rz) + nry + nrx + nineq * mu;
+        if (!have_best || resid < best) {
+            best = resid; have_best = 1; not_improved = 0;
+            if (lane < nz) x_out[lane] = L.xv[lane];
+            else if (lane < n) nu[lane - nz] = L.xv[lane];
+            for (int c = lane; c < nc; c += WAVE)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    lam[(size_t)q * maxc + c] = cz[(size_t)q * maxc + c];
+                    slack[(size_t)q * maxc + c] = cs[(size_t)q * maxc + c];
+                }
+        } else {
+            ++not_improved;
+        }
+        if (not_improved == not_improved_lim || best < eps || mu > 1e32) break;
+
+        // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
+        __syncthreads();
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double a[NR], C[9];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) a[q] = cs[(size_t)q * maxc + c] / cz[(size_t)q * maxc + c];
+            c_mat<ND>(g, a, C);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
+        }
+        __syncthreads();
+        assemble_K(L, Mblk, A, cbody, nc);
+        factor_K(L);
+        {
+            double rhs = 0.0;
+            if (lane < nz) rhs = -rx - L.g2[lane];
+            else if (lane < n) rhs = -ry;
+            const double sol = solve_K(L, rhs);
+            if (lane < n) L.dxa[lane] = sol;
+        }
+        __syncthreads();
+        StepAcc stz, sts;
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double s[NR], z[NR], a[NR], r[NR], u[NR], vr[3];
+            rel_vel<ND>(L.dxa, g, vr);
+            g_rows<ND>(g, vr, r);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                s[q] = cs[(size_t)q * maxc + c]; z[q] = cz[(size_t)q * maxc + c];
+                a[q] = s[q] / z[q];
+                r[q] += crz[(size_t)q * maxc + c] - s[q];
+            }
+            w_apply<ND>(g.mu, a, r, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double dz = u[q], ds = (-z[q] - dz) / (z[q] / s[q]);
+                cdz[(size_t)q * maxc + c] = dz;
+                cds[(size_t)q * maxc + c] = ds;
+                stz.add(z[q], dz);
+                sts.add(s[q], ds);
+            }
+        }
+        double alpha = fmin(fmin(stz.finish(), sts.finish()), 1.0);
+        __syncthreads();
+        double t3 = 0.0;
+        for (int c = lane; c < nc; c += WAVE)
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+                t3 += (cs[(size_t)q * maxc + c] + alpha * cds[(size_t)q * maxc + c]) *
+                      (cz[(size_t)q * maxc + c] + alpha * cdz[(size_t)q * maxc + c]);
+        t3 = wave_sum(t3);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // ---- corrector (batch.py:194-205): rx = rz = ry = 0, rs = (-mu sig + ds dz)/s ----------
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double a[NR], t[NR], u[NR], w[3];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double s = cs[(size_t)q * maxc + c], z = cz[(size_t)q * maxc + c];
+                const double rs2 = (-mu * sig + cds[(size_t)q * maxc + c] * cdz[(size_t)q * maxc + c]) / s;
+                a[q] = s / z;
+                t[q] = rs2 / (z / s);
+            }
+            w_apply<ND>(g.mu, a, t, u);
+            w_vec<ND>(g, u, w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = w[j];
+        }
+        __syncthreads();
+        gather<1>(L, L.g1, nullptr);
+        {
+            double rhs = (lane < nz) ? L.g1[lane] : 0.0;
+            const double sol = solve_K(L, rhs);
+            if (lane < n) L.sol[lane] = sol;
+        }
+        __syncthreads();
+        StepAcc stz2, sts2;
+        for (int c = lane; c < nc; c += WAVE) {
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double s[NR], z[NR], a[NR], r[NR], u[NR], rs2[NR], vr[3];
+            rel_vel<ND>(L.sol, g, vr);
+            g_rows<ND>(g, vr, r);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                s[q] = cs[(size_t)q * maxc + c]; z[q] = cz[(size_t)q * maxc + c];
+                rs2[q] = (-mu * sig + cds[(size_t)q * maxc + c] * cdz[(size_t)q * maxc + c]) / s[q];
+                a[q] = s[q] / z[q];
+                r[q] -= rs2[q] / (z[q] / s[q]);
+            }
+            w_apply<ND>(g.mu, a, r, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double dz = cdz[(size_t)q * maxc + c] + u[q];
+                const double ds = cds[(size_t)q * maxc + c] + (-rs2[q] - u[q]) / (z[q] / s[q]);
+                cdz[(size_t)q * maxc + c] = dz;
+                cds[(size_t)q * maxc + c] = ds;
+                stz2.add(z[q], dz);
+                sts2.add(s[q], ds);
+            }
+        }
+        alpha = fmin(0.999 * fmin(stz2.finish(), sts2.finish()), 1.0);
+        __syncthreads();
+        if (lane < n) L.xv[lane] += alpha * (L.dxa[lane] + L.sol[lane]);
+        for (int c = lane; c < nc; c += WAVE)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                cs[(size_t)q * maxc + c] += alpha * cds[(size_t)q * maxc + c];
+                cz[(size_t)q * maxc + c] += alpha * cdz[(size_t)q * maxc + c];
+            }
+        __syncthreads();
+    }
+    if (lane == 0) { iters[sc] = it; status[sc] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
+}
+
+// Implicit backward (lcp.py:156-213) in the same reduced form; gradients come out already
+// contracted onto the contact operands (directions, contact points, mu, h_n), the mass blocks
+// and the linear term -- the dense dG / dF of the reference are never formed.
+template <int ND>
+__global__ void __launch_bounds__(64)
+lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double *cop_, const int *cbody_,
+                            const int *ncs, int nb, int neq, int maxc, const double *x_, const double *lam_,
+                            const double *slack_, const double *nu_, const double *dl_dx_, double *dMblk_,
+                            double *dpvec_, double *dcop_, double *dA_, double *db_)
+{
+    constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
+    DSS_DYN_LDS(double, ldsmem);
+    const int sc = blockIdx.x, lane = lane_id();
+    Lds L;
+    carve_lds(L, ldsmem, nb, neq, maxc);
+    const int nz = L.nz, n = L.n;
+    const double *Mblk = Mblk_ + (size_t)sc * nb * 36;
+    const double *A = neq ? A_ + (size_t)sc * neq * nz : nullptr;
+    const double *cop = cop_ + (size_t)sc * NF * maxc;
+    const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
+    const double *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
+    double *dcop = dcop_ + (size_t)sc * NF * maxc;
+    int nc = ncs[sc];
+    if (nc > maxc) nc = maxc;
+
+    for (int c = lane; c < nc; c += WAVE) {
+        const int o = 3 * (1 + ND);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) L.pbuf[6 * c + j] = cop[(size_t)(o + j) * maxc + c];
+    }
+    if (lane < nz) L.xv[lane] = x_[(size_t)sc * nz + lane];
+    else if (lane < n) L.xv[lane] = nu_[(size_t)sc * neq + lane - nz];
+    __syncthreads();
+    for (int c = lane; c < nc; c += WAVE) {
+        Geo<ND> g;
+        load_geo<ND>(g, cop, cbody, maxc, c);
+        double a[NR], C[9];
+#pragma unroll
+        for (int q = 0; q < NR; ++q)  // d = clamp(lam)/clamp(slack), lcp.py:176
+            a[q] = fmax(slack[(size_t)q * maxc + c], 1e-8) / fmax(lam[(size_t)q * maxc + c], 1e-8);
+        c_mat<ND>(g, a, C);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
+    }
+    __syncthreads();
+    assemble_K(L, Mblk, A, cbody, nc);
+    factor_K(L);
+    {
+        const double rhs = (lane < nz) ? -dl_dx_[(size_t)sc * nz + lane] : 0.0;
+        const double sol = solve_K(L, rhs);
+        if (lane < n) L.sol[lane] = sol;
+    }
+    __syncthreads();
+    const double *dx = L.sol, *zx = L.xv;
+    // dQ (block diagonal part), dp, dA, db
+    for (int e = lane; e < nb * 36; e += WAVE) {
+        const int b = e / 36, i = 6 * b + (e % 36) / 6, j = 6 * b + e % 6;
+        dMblk_[(size_t)sc * nb * 36 + e] = 0.5 * (dx[i] * zx[j] + zx[i] * dx[j]);
+    }
+    if (lane < nz) dpvec_[(size_t)sc * nz + lane] = dx[lane];
+    if (dA_)
+        for (int e = lane; e < neq * nz; e += WAVE) {
+            const int i = e / nz, j = e % nz;
+            dA_[(size_t)sc * neq * nz + e] = dx[nz + i] * zx[j] + zx[nz + i] * dx[j];
+        }
+    if (db_ && lane < neq) db_[(size_t)sc * neq + lane] = -dx[nz + lane];
+    for (int c = lane; c < maxc; c += WAVE) {
+        if (c >= nc) {
+            for (int f = 0; f < NF; ++f) dcop[(size_t)f * maxc + c] = 0.0;
+            continue;
+        }
+        Geo<ND> g;
+        load_geo<ND>(g, cop, cbody, maxc, c);
+        double a[NR], l[NR], r[NR], dl[NR], vrx[3], vrz[3], wl[3], wdl[3], t1[3], t2[3];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            l[q] = lam[(size_t)q * maxc + c];
+            a[q] = fmax(slack[(size_t)q * maxc + c], 1e-8) / fmax(l[q], 1e-8);
+        }
+        rel_vel<ND>(dx, g, vrx);
+        rel_vel<ND>(zx, g, vrz);
+        g_rows<ND>(g, vrx, r);
+        w_apply<ND>(g.mu, a, r, dl);  // dlam = W G dx
+        // directions
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dcop[(size_t)j * maxc + c] = dl[0] * vrz[j] + l[0] * vrx[j];
+#pragma unroll
+        for (int k = 1; k <= ND; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dcop[(size_t)(3 * k + j) * maxc + c] = (dl[k] - dl[ND + k]) * vrz[j] + (l[k] - l[ND + k]) * vrx[j];
+        // contact points
+        w_vec<ND>(g, l, wl);
+        w_vec<ND>(g, dl, wdl);
+        const int o = 3 * (1 + ND);
+        cross3(wdl, zx + 6 * g.b1, t1);
+        cross3(wl, dx + 6 * g.b1, t2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dcop[(size_t)(o + j) * maxc + c] = t1[j] + t2[j];
+        cross3(wdl, zx + 6 * g.b2, t1);
+        cross3(wl, dx + 6 * g.b2, t2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dcop[(size_t)(o + 3 + j) * maxc + c] = -(t1[j] + t2[j]);
+        dcop[(size_t)(o + 6) * maxc + c] = dl[NR - 1] * l[0];  // dF[cone_c, normal_c] = dlam_cone lam_n
+        dcop[(size_t)(o + 7) * maxc + c] = -dl[0];             // dh_n = -dlam_n
+    }
+}
+
+inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
+{
+    return B > 0 && nb > 0 && neq >= 0 && maxc > 0 && (fd == 4 || fd == 8);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dss_lcp_contact_workspace_bytes(int B, int nb, int neq, int maxc, int fric_dirs)
+{
+    if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return 0;
+    return (size_t)B * 5 * (fric_dirs + 2) * maxc * sizeof(double);
+}
+
+int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double *A, const double *bvec,
+                            const double *cop, const int *cbody, const int *nc, int B, int nb, int neq, int maxc,
+                            int fric_dirs, double eps, int not_improved_lim, int max_iter, double *x, double *lam,
+                            double *slack, double *nu, int *iters, int *status, void *workspace,
+                            size_t workspace_bytes, void *stream)
+{
+    if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return DSS_E_BADARG;
+    if (!Mblk || !pvec || !cop || !cbody || !nc || !x || !lam || !slack || !iters || !status || !workspace) return DSS_E_BADARG;
+    if (neq > 0 && (!A || !bvec || !nu)) return DSS_E_BADARG;
+    if (6 * nb + neq > 64) return DSS_E_UNSUPPORTED;
+    if (workspace_bytes < dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fric_dirs)) return DSS_E_WORKSPACE;
+    const size_t lds = lds_bytes(nb, neq, maxc);
+    if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
+    if (fric_dirs == 8)
+        hipLaunchKernelGGL(lcp_contact_forward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
+                           cop, cbody, nc, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
+                           status, (double *)workspace);
+    else
+        hipLaunchKernelGGL(lcp_contact_forward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
+                           cop, cbody, nc, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
+                           status, (double *)workspace);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
+                             int B, int nb, int neq, int maxc, int fric_dirs, const double *x, const double *lam,
+                             const double *slack, const double *nu, const double *dl_dx, double *dMblk,
+                             double *dpvec, double *dcop, double *dA, double *db, void *stream)
+{
+    if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return DSS_E_BADARG;
+    if (!Mblk || !cop || !cbody || !nc || !x || !lam || !slack || !dl_dx || !dMblk || !dpvec || !dcop) return DSS_E_BADARG;
+    if (neq > 0 && (!A || !nu)) return DSS_E_BADARG;
+    if (6 * nb + neq > 64) return DSS_E_UNSUPPORTED;
+    const size_t lds = lds_bytes(nb, neq, maxc);
+    if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
+    if (fric_dirs == 8)
+        hipLaunchKernelGGL(lcp_contact_backward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
+                           nc, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+    else
+        hipLaunchKernelGGL(lcp_contact_backward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
+                           nc, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -65,6 +65,36 @@ int dss_lcp_dense_backward(const double *Q, const double *G, const double *A, co
                            double *dQ, double *dp, double *dG, double *dh, double *dA, double *db, double *dF,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * B2: contact-structured LCP  --  what lcp_physics.physics.engines.PdipmEngine.solve_dynamics
+ *     (engines.py:56-82) hands to LCPFunction, without ever forming the dense G and F:
+ *       Q  = blockdiag(Mblk[b])  (6x6 per body),  p = pvec,  A/b = equality rows,
+ *       contact c between bodies cbody[0][c], cbody[1][c] with unit directions D_0 = n and
+ *       D_1..D_ND (ND = fric_dirs/2; the reference appends -D_k, physics3d/world.py:84-94),
+ *       contact points p1, p2 (world-frame offsets from the body origins), mu_c, h_c.
+ *     Row order inside a contact: [n, +D_1..+D_ND, -D_1..-D_ND, cone]; the matching dense
+ *     order of the reference is  n -> c,  k-th friction row -> nc + c*fd + k,  cone -> nc+nc*fd+c.
+ *   cop   [B][NF][maxc]  NF = 3*(1+ND)+8 : D_0..D_ND (3 each), p1(3), p2(3), mu, h_n   (SoA)
+ *   cbody [B][2][maxc]   int32;   nc [B] int32 (contacts beyond nc[s] are ignored)
+ *   lam/slack [B][NR][maxc], NR = fric_dirs+2.   Limits: 6*nb+neq <= 64 (one wavefront).
+ *   backward (lcp.py:156-213): dMblk [B][nb][36], dpvec [B][nz], dcop like cop (d/dD, d/dp1,
+ *   d/dp2, d/dmu, d/dh_n); dA [B][neq][nz] and db [B][neq] may be NULL.
+ * ------------------------------------------------------------------------------------ */
+size_t dss_lcp_contact_workspace_bytes(int B, int nb, int neq, int maxc, int fric_dirs);
+
+int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double *A, const double *bvec,
+                            const double *cop, const int *cbody, const int *nc,
+                            int B, int nb, int neq, int maxc, int fric_dirs,
+                            double eps, int not_improved_lim, int max_iter,
+                            double *x, double *lam, double *slack, double *nu, int *iters, int *status,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *cop, const int *cbody,
+                             const int *nc, int B, int nb, int neq, int maxc, int fric_dirs,
+                             const double *x, const double *lam, const double *slack, const double *nu,
+                             const double *dl_dx,
+                             double *dMblk, double *dpvec, double *dcop, double *dA, double *db, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

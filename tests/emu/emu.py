@@ -57,3 +57,36 @@ def lcp_dense_backward(Q, G, A, F, zhat, lam, slack, nu, dl):
                                   ctypes.c_size_t(nbytes), None)
     assert rc == 0, rc
     return dQ, dp, dG, dh, dA, db, dF
+
+
+def lcp_contact_forward(P, eps=1e-12, nil=3, max_iter=10):
+    L = lib()
+    L.dss_lcp_contact_workspace_bytes.restype = ctypes.c_size_t
+    B, nb, neq, maxc, fd = P["Mblk"].shape[0], P["nb"], P["neq"], P["maxc"], P["fd"]
+    NR = fd + 2; nz = 6 * nb
+    Mblk, pvec, A, bvec, cop = (_c(P[k]) for k in ("Mblk", "pvec", "A", "bvec", "cop"))
+    cbody, nc = _c(P["cbody"], np.int32), _c(P["nc"], np.int32)
+    x = np.zeros((B, nz)); lam = np.zeros((B, NR, maxc)); slack = np.zeros((B, NR, maxc)); nu = np.zeros((B, neq))
+    iters = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
+    nbytes = L.dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fd)
+    ws = np.zeros(nbytes, np.uint8)
+    rc = L.dss_lcp_contact_forward(_p(Mblk), _p(pvec), _p(A), _p(bvec), _p(cop), _p(cbody), _p(nc), B, nb, neq, maxc, fd,
+                                   ctypes.c_double(eps), nil, max_iter, _p(x), _p(lam), _p(slack), _p(nu), _p(iters),
+                                   _p(status), _p(ws), ctypes.c_size_t(nbytes), None)
+    assert rc == 0, rc
+    return x, lam, slack, nu, iters, status
+
+
+def lcp_contact_backward(P, x, lam, slack, nu, dl):
+    L = lib()
+    B, nb, neq, maxc, fd = P["Mblk"].shape[0], P["nb"], P["neq"], P["maxc"], P["fd"]
+    nz = 6 * nb; NF = 3 * (1 + fd // 2) + 8
+    Mblk, A, cop = (_c(P[k]) for k in ("Mblk", "A", "cop"))
+    cbody, nc = _c(P["cbody"], np.int32), _c(P["nc"], np.int32)
+    x, lam, slack, nu, dl = (_c(v) for v in (x, lam, slack, nu, dl))
+    dM = np.zeros((B, nb, 6, 6)); dp = np.zeros((B, nz)); dcop = np.zeros((B, NF, maxc))
+    dA = np.zeros((B, neq, nz)); db = np.zeros((B, neq))
+    rc = L.dss_lcp_contact_backward(_p(Mblk), _p(A), _p(cop), _p(cbody), _p(nc), B, nb, neq, maxc, fd, _p(x), _p(lam),
+                                    _p(slack), _p(nu), _p(dl), _p(dM), _p(dp), _p(dcop), _p(dA), _p(db), None)
+    assert rc == 0, rc
+    return dM, dp, dcop, dA, db
