@@ -1,0 +1,81 @@
+// contact_geom.h -- contact point geometry shared by the narrow phase (T = double) and its
+// backward (T = Dual<N>).  Restates FWContactHandler._compute_contacts
+// (sdf_physics/physics3d/contacts.py:161-214) for SDF-SDF pairs.
+#pragma once
+#include "geom.h"
+
+namespace dss {
+
+template <class T> struct BodyG {
+    T q[4], pos[3];
+    Shape<T> shape;
+};
+
+// Laplacian probe of phi by central second differences with step h (values only; the reference
+// uses it in a comparison, contacts.py:184-198, so it carries no gradient).
+template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s, const T *p, double phi0, double h)
+{
+    Shape<double> sd;
+    sd.type = s.type;
+    for (int i = 0; i < 3; ++i) sd.prm[i] = val(s.prm[i]);
+    sd.scale = val(s.scale);
+    double acc = 0.0, pt[3] = {val(p[0]), val(p[1]), val(p[2])}, g[3];
+    for (int i = 0; i < 3; ++i) {
+        double a, b, save = pt[i];
+        pt[i] = save + h; query_sdf(sd, pt, a, g, false);
+        pt[i] = save - h; query_sdf(sd, pt, b, g, false);
+        pt[i] = save;
+        acc += a - 2.0 * phi0 + b;
+    }
+    return acc;
+}
+
+// One contact from a barycentric point on a triangle of body 1's mesh.
+//   tri: the three vertices (body-1 frame), abc: barycentrics (constants)
+//   out: n (world), p1, p2 (world-frame offsets from the body origins), pen = -phi_2
+template <class T>
+__host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const BodyG<T> &b2, const T tri[3][3],
+                                                  const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen)
+{
+    T cp1[3], d1, n1[3], cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
+    for (int i = 0; i < 3; ++i) cp1[i] = tri[0][i] * abc[0] + tri[1][i] * abc[1] + tri[2][i] * abc[2];
+    // the triangle point is pulled onto body 1's true surface by one Newton step (contacts.py:169-171)
+    query_sdf(b1.shape, cp1, d1, n1, true);
+    for (int i = 0; i < 3; ++i) cp1[i] = cp1[i] - d1 * n1[i];
+    query_sdf(b1.shape, cp1, d1, n1, true);
+    quat_apply(b1.q, cp1, p1);
+    for (int i = 0; i < 3; ++i) { cpw[i] = p1[i] + b1.pos[i]; rel[i] = cpw[i] - b2.pos[i]; }
+    quat_apply_inv(b2.q, rel, cp2);
+    query_sdf(b2.shape, cp2, d2, n2, true);
+    const double l1 = lap_probe(b1.shape, cp1, val(d1), lap_h), l2 = lap_probe(b2.shape, cp2, val(d2), lap_h);
+    const bool stable = fabs(l2) < fabs(l1);
+    if (stable) {
+        quat_apply(b2.q, n2, n);
+    } else {
+        quat_apply(b1.q, n1, t);
+        for (int i = 0; i < 3; ++i) n[i] = -t[i];
+    }
+    for (int i = 0; i < 3; ++i) t[i] = cp2[i] - d2 * n2[i];
+    quat_apply(b2.q, t, p2);
+    pen = -d2;
+}
+
+// friction directions of World3D.Jf (physics3d/world.py:84-94; utils.py:247-256 `orthogonal`)
+template <class T> __host__ __device__ inline void friction_dirs(const T *n, int nd, T D[][3])
+{
+    int am = 0;
+    for (int i = 1; i < 3; ++i) if (fabs(val(n[i])) < fabs(val(n[am]))) am = i;
+    T e[3] = {T(am == 0 ? 1.0 : 0.0), T(am == 1 ? 1.0 : 0.0), T(am == 2 ? 1.0 : 0.0)}, t[3];
+    cross(e, n, t);
+    normalize(t, D[0]);
+    cross(D[0], n, t);
+    normalize(t, D[1]);
+    if (nd == 4) {
+        for (int i = 0; i < 3; ++i) t[i] = D[0][i] + D[1][i];
+        normalize(t, D[2]);
+        cross(D[2], n, t);
+        normalize(t, D[3]);
+    }
+}
+
+}  // namespace dss

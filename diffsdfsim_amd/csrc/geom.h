@@ -1,0 +1,281 @@
+// geom.h -- scalar-generic rigid-body / SDF geometry for the stepper kernels.
+//
+// Every function is a template on the scalar type T: `double` in the forward kernels and
+// Dual<N> (value + N tangents) in the backward kernels, which obtain the vector-Jacobian
+// product of a small stage (contact geometry, pose integration, world-frame inertia) by
+// seeding its inputs and contracting the output tangents with the incoming adjoint.
+// The derivative conventions follow what torch.autograd does in the reference for the
+// non-smooth pieces (abs'(0) = 0, clamp passes the gradient on the boundary, max/min route
+// the gradient to one arg-max, F.normalize clamps the norm at 1e-12).
+//
+// Conventions: quaternions are real-first (w,x,y,z); pose = [q(4), x(3)];
+// generalized velocity = [omega(3), v(3)]; pytorch3d==0.7.5 semantics (restated, not vendored):
+//   so3_exponential_map clamps |v|^2 at eps = 1e-4 before the square root,
+//   quaternion_multiply standardises to a non-negative real part,
+//   matrix_to_quaternion picks the best conditioned of four candidates.
+#pragma once
+#include <math.h>
+
+#include "dss_device.h"
+
+namespace dss {
+
+template <int N> struct Dual {
+    double v;
+    double d[N];
+    __host__ __device__ Dual() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+    __host__ __device__ Dual(double x) : v(x) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+};
+
+__host__ __device__ inline double val(double x) { return x; }
+template <int N> __host__ __device__ inline double val(const Dual<N> &x) { return x.v; }
+
+#define DSS_DUAL_BIN(op, expr_v, expr_d)                                                                  \
+    template <int N> __host__ __device__ inline Dual<N> operator op(const Dual<N> &a, const Dual<N> &b)   \
+    {                                                                                                      \
+        Dual<N> r;                                                                                         \
+        r.v = expr_v;                                                                                      \
+        for (int i = 0; i < N; ++i) r.d[i] = expr_d;                                                       \
+        return r;                                                                                          \
+    }
+DSS_DUAL_BIN(+, a.v + b.v, a.d[i] + b.d[i])
+DSS_DUAL_BIN(-, a.v - b.v, a.d[i] - b.d[i])
+DSS_DUAL_BIN(*, a.v * b.v, a.d[i] * b.v + a.v * b.d[i])
+DSS_DUAL_BIN(/, a.v / b.v, (a.d[i] - (a.v / b.v) * b.d[i]) / b.v)
+#undef DSS_DUAL_BIN
+template <int N> __host__ __device__ inline Dual<N> operator+(const Dual<N> &a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> __host__ __device__ inline Dual<N> operator+(double b, const Dual<N> &a) { return a + b; }
+template <int N> __host__ __device__ inline Dual<N> operator-(const Dual<N> &a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> __host__ __device__ inline Dual<N> operator-(double b, const Dual<N> &a)
+{
+    Dual<N> r; r.v = b - a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r;
+}
+template <int N> __host__ __device__ inline Dual<N> operator-(const Dual<N> &a)
+{
+    Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r;
+}
+template <int N> __host__ __device__ inline Dual<N> operator*(const Dual<N> &a, double b)
+{
+    Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r;
+}
+template <int N> __host__ __device__ inline Dual<N> operator*(double b, const Dual<N> &a) { return a * b; }
+template <int N> __host__ __device__ inline Dual<N> operator/(const Dual<N> &a, double b) { return a * (1.0 / b); }
+template <int N> __host__ __device__ inline Dual<N> operator/(double b, const Dual<N> &a) { return Dual<N>(b) / a; }
+
+__host__ __device__ inline double t_sqrt(double x) { return sqrt(x); }
+template <int N> __host__ __device__ inline Dual<N> t_sqrt(const Dual<N> &a)
+{
+    Dual<N> r; r.v = sqrt(a.v);
+    const double k = a.v > 0.0 ? 0.5 / r.v : 0.0;
+    for (int i = 0; i < N; ++i) r.d[i] = k * a.d[i];
+    return r;
+}
+__host__ __device__ inline double t_sin(double x) { return sin(x); }
+__host__ __device__ inline double t_cos(double x) { return cos(x); }
+template <int N> __host__ __device__ inline Dual<N> t_sin(const Dual<N> &a)
+{
+    Dual<N> r; r.v = sin(a.v); const double c = cos(a.v);
+    for (int i = 0; i < N; ++i) r.d[i] = c * a.d[i];
+    return r;
+}
+template <int N> __host__ __device__ inline Dual<N> t_cos(const Dual<N> &a)
+{
+    Dual<N> r; r.v = cos(a.v); const double s = -sin(a.v);
+    for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i];
+    return r;
+}
+// torch.abs: d/dx = sign(x), 0 at 0
+__host__ __device__ inline double t_abs(double x) { return fabs(x); }
+template <int N> __host__ __device__ inline Dual<N> t_abs(const Dual<N> &a)
+{
+    const double s = a.v > 0.0 ? 1.0 : (a.v < 0.0 ? -1.0 : 0.0);
+    Dual<N> r; r.v = fabs(a.v);
+    for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i];
+    return r;
+}
+// clamp(x, min=lo): gradient passes when x >= lo (torch.clamp backward mask is x >= min)
+template <class T> __host__ __device__ inline T t_clamp_min(const T &x, double lo) { return val(x) >= lo ? x : T(lo); }
+template <class T> __host__ __device__ inline T t_clamp_max(const T &x, double hi) { return val(x) <= hi ? x : T(hi); }
+// select by value; ties go to the first argument (index-0-wins like torch.max(dim).indices on CPU)
+template <class T> __host__ __device__ inline T t_max(const T &a, const T &b) { return val(b) > val(a) ? b : a; }
+template <class T> __host__ __device__ inline T t_min(const T &a, const T &b) { return val(b) < val(a) ? b : a; }
+
+template <class T> struct V3 { T x[3]; };
+
+template <class T> __host__ __device__ inline void cross(const T *a, const T *b, T *o)
+{
+    T o0 = a[1] * b[2] - a[2] * b[1], o1 = a[2] * b[0] - a[0] * b[2], o2 = a[0] * b[1] - a[1] * b[0];
+    o[0] = o0; o[1] = o1; o[2] = o2;
+}
+template <class T> __host__ __device__ inline T dot(const T *a, const T *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class T> __host__ __device__ inline T norm3(const T *a) { return t_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+// torch.nn.functional.normalize(v, dim): v / max(||v||, 1e-12)
+template <class T> __host__ __device__ inline void normalize(const T *a, T *o)
+{
+    T n = norm3(a);
+    if (val(n) < 1e-12) n = T(1e-12);
+    for (int i = 0; i < 3; ++i) o[i] = a[i] / n;
+}
+
+// ---- quaternions (pytorch3d.transforms semantics) -------------------------------------------
+template <class T> __host__ __device__ inline void quat_raw_mul(const T *a, const T *b, T *o)
+{
+    T ow = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    T ox = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    T oy = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    T oz = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    o[0] = ow; o[1] = ox; o[2] = oy; o[3] = oz;
+}
+template <class T> __host__ __device__ inline void quat_mul(const T *a, const T *b, T *o)
+{
+    quat_raw_mul(a, b, o);
+    if (val(o[0]) < 0.0) for (int i = 0; i < 4; ++i) o[i] = -o[i];
+}
+template <class T> __host__ __device__ inline void quat_inv(const T *q, T *o)
+{
+    o[0] = q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = -q[3];
+}
+// quaternion_apply(q, p) = (q * (0,p) * q^-1)[1:]   (no normalisation, as in pytorch3d)
+template <class T> __host__ __device__ inline void quat_apply(const T *q, const T *p, T *o)
+{
+    T pq[4] = {T(0.0), p[0], p[1], p[2]}, qi[4], t[4], r[4];
+    quat_inv(q, qi);
+    quat_raw_mul(q, pq, t);
+    quat_raw_mul(t, qi, r);
+    o[0] = r[1]; o[1] = r[2]; o[2] = r[3];
+}
+template <class T> __host__ __device__ inline void quat_apply_inv(const T *q, const T *p, T *o)
+{
+    T qi[4];
+    quat_inv(q, qi);
+    quat_apply(qi, p, o);
+}
+template <class T> __host__ __device__ inline void quat_to_mat(const T *q, T *R /*[9] row-major*/)
+{
+    const T r = q[0], i = q[1], j = q[2], k = q[3];
+    const T two_s = 2.0 / (r * r + i * i + j * j + k * k);
+    R[0] = 1.0 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1.0 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.0 - two_s * (i * i + j * j);
+}
+// so3_exponential_map(v, eps=1e-4)
+template <class T> __host__ __device__ inline void so3_exp(const T *w, T *R)
+{
+    T nr = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    nr = t_clamp_min(nr, 1e-4);
+    const T ang = t_sqrt(nr), inv = 1.0 / ang;
+    const T f1 = inv * t_sin(ang), f2 = inv * inv * (1.0 - t_cos(ang));
+    const T K[9] = {T(0.0), -w[2], w[1], w[2], T(0.0), -w[0], -w[1], w[0], T(0.0)};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            T k2 = K[3 * a] * K[b] + K[3 * a + 1] * K[3 + b] + K[3 * a + 2] * K[6 + b];
+            R[3 * a + b] = f1 * K[3 * a + b] + f2 * k2 + (a == b ? 1.0 : 0.0);
+        }
+}
+template <class T> __host__ __device__ inline T sqrt_pos(const T &x) { return val(x) > 0.0 ? t_sqrt(x) : T(0.0); }
+template <class T> __host__ __device__ inline void mat_to_quat(const T *m, T *q)
+{
+    const T qa[4] = {sqrt_pos(1.0 + m[0] + m[4] + m[8]), sqrt_pos(1.0 + m[0] - m[4] - m[8]),
+                     sqrt_pos(1.0 - m[0] + m[4] - m[8]), sqrt_pos(1.0 - m[0] - m[4] + m[8])};
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (val(qa[i]) > val(qa[best])) best = i;
+    T c[4];
+    switch (best) {
+    case 0: c[0] = qa[0] * qa[0]; c[1] = m[7] - m[5]; c[2] = m[2] - m[6]; c[3] = m[3] - m[1]; break;
+    case 1: c[0] = m[7] - m[5]; c[1] = qa[1] * qa[1]; c[2] = m[3] + m[1]; c[3] = m[2] + m[6]; break;
+    case 2: c[0] = m[2] - m[6]; c[1] = m[3] + m[1]; c[2] = qa[2] * qa[2]; c[3] = m[5] + m[7]; break;
+    default: c[0] = m[3] - m[1]; c[1] = m[6] + m[2]; c[2] = m[7] + m[5]; c[3] = qa[3] * qa[3]; break;
+    }
+    T den = qa[best];
+    if (val(den) < 0.1) den = T(0.1);
+    den = den * 2.0;
+    for (int i = 0; i < 4; ++i) q[i] = c[i] / den;
+    if (val(q[0]) < 0.0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+}
+
+// Body3D.move (physics3d/bodies.py:488-496): q <- quat(exp(w dt)) (x) q ; x <- x + v dt
+template <class T> __host__ __device__ inline void integrate_pose(const T *pose, const T *vel, const T &dt, T *out)
+{
+    T w[3] = {vel[0] * dt, vel[1] * dt, vel[2] * dt}, R[9], dq[4];
+    so3_exp(w, R);
+    mat_to_quat(R, dq);
+    quat_mul(dq, pose, out);
+    for (int i = 0; i < 3; ++i) out[4 + i] = pose[4 + i] + vel[3 + i] * dt;
+}
+
+// world-frame rotational inertia R I R^T (physics3d/bodies.py:509-511)
+template <class T> __host__ __device__ inline void world_inertia(const T *q, const T *Ib /*[9]*/, T *out /*[9]*/)
+{
+    T R[9], t[9];
+    quat_to_mat(q, R);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) t[3 * a + b] = R[3 * a] * Ib[b] + R[3 * a + 1] * Ib[3 + b] + R[3 * a + 2] * Ib[6 + b];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) out[3 * a + b] = t[3 * a] * R[3 * b] + t[3 * a + 1] * R[3 * b + 1] + t[3 * a + 2] * R[3 * b + 2];
+}
+
+// ---- primitive SDFs (physics3d/bodies.py:38-95) and SDF3D.query_sdfs (:721-760) -------------
+enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1 };
+
+template <class T> struct Shape {
+    int type;
+    T prm[3];   // box: dims ; sphere: rad
+    T scale;    // box: 1.5*max(dims)/2 ; sphere: 1.5*rad   (bodies.py:782, 987)
+};
+template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int type, const T *prm)
+{
+    s.type = type;
+    for (int i = 0; i < 3; ++i) s.prm[i] = prm[i];
+    if (type == SHAPE_BOX) s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
+    else s.scale = prm[0] * 1.5;
+}
+
+// value and (normalised) gradient of the unit-cube SDF at p = pts/scale, parameters prm/scale
+template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, const T *p, T &phi, T *g, bool want_grad)
+{
+    if (s.type == SHAPE_BOX) {
+        T q[3], m[3], hd[3];
+        for (int i = 0; i < 3; ++i) { hd[i] = (s.prm[i] / s.scale) / 2.0; q[i] = t_abs(p[i]) - hd[i]; }
+        const T md = t_max(t_max(q[0], q[1]), q[2]);
+        for (int i = 0; i < 3; ++i) m[i] = t_clamp_min(q[i], 0.0);
+        phi = norm3(m) + t_clamp_max(md, 0.0);
+        if (want_grad) {
+            // box_sdf_grad: failsafe diagonal normals on ties (bodies.py:51-72); m = max(q, 0)
+            T mg[3], nm[3], go[3];
+            for (int i = 0; i < 3; ++i) mg[i] = t_max(q[i], T(0.0));
+            normalize(mg, nm);
+            for (int i = 0; i < 3; ++i) {
+                const double sg = val(p[i]) < 0.0 ? -1.0 : 1.0;
+                const double md_dir = (val(md) <= 0.0 && val(q[i]) == val(md)) ? 1.0 : 0.0;
+                go[i] = (nm[i] + md_dir) * sg;
+            }
+            T g1[3];
+            normalize(go, g1);
+            normalize(g1, g);  // query_sdfs normalises again (bodies.py:748)
+        }
+    } else {
+        const T n = norm3(p);
+        phi = n - s.prm[0] / s.scale;
+        if (want_grad) { T g1[3]; normalize(p, g1); normalize(g1, g); }
+    }
+}
+
+// SDF3D.query_sdfs: outside the [-scale, scale]^3 box: phi = scale, grad = 0
+template <class T> __host__ __device__ inline bool query_sdf(const Shape<T> &s, const T *pt, T &phi, T *g, bool want_grad)
+{
+    const double sc = val(s.scale);
+    const bool inside = fabs(val(pt[0])) <= sc && fabs(val(pt[1])) <= sc && fabs(val(pt[2])) <= sc;
+    if (!inside) {
+        phi = s.scale;  // sdfs = ones * scale
+        if (want_grad) for (int i = 0; i < 3; ++i) g[i] = T(0.0);
+        return false;
+    }
+    T p[3];
+    for (int i = 0; i < 3; ++i) p[i] = pt[i] / s.scale;
+    T u;
+    sdf_unit(s, p, u, g, want_grad);
+    phi = u * s.scale;
+    return true;
+}
+
+}  // namespace dss

@@ -154,6 +154,7 @@ struct Lds {
     int *piv;       // [n]
     int *bl_start;  // [nb+1]
     int *bl_ent;    // [2*maxc]  contact*2 + side
+    int *cb;        // [2][maxc] body ids (LDS copy)
     int n, lda, nz, neq, nb, maxc;
 };
 
@@ -165,7 +166,7 @@ __host__ __device__ inline size_t lds_doubles(int nb, int neq, int maxc)
 __host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
 {
     const int n = 6 * nb + neq;
-    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 2 * maxc + 4) * 4;
+    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 4 * maxc + 4) * 4;
 }
 __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc)
 {
@@ -184,13 +185,17 @@ __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc
     int *ip = reinterpret_cast<int *>(q);
     L.piv = ip; ip += L.n;
     L.bl_start = ip; ip += nb + 1;
-    L.bl_ent = ip;
+    L.bl_ent = ip; ip += 2 * maxc;
+    L.cb = ip;
 }
 
 // per-body contact lists in ascending contact order (deterministic gathers)
-__device__ void build_lists(Lds &L, const int *cbody, int nc)
+__device__ void build_lists(Lds &L, const int *cbody_g, int nc)
 {
     const int lane = lane_id();
+    for (int c = lane; c < nc; c += WAVE) { L.cb[c] = cbody_g[c]; L.cb[L.maxc + c] = cbody_g[L.maxc + c]; }
+    __syncthreads();
+    const int *cbody = L.cb;
     if (lane < L.nb) {
         int cnt = 0;
         for (int c = 0; c < nc; ++c) cnt += (cbody[c] == lane) + (cbody[L.maxc + c] == lane);
@@ -244,8 +249,9 @@ template <int NP> __device__ void gather(const Lds &L, double *out0, double *out
 }
 
 // K = [[Q + sum_c P C P^T, A^T],[A, 0]]  (C matrices in L.cw, 9 per contact)
-__device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const int *cbody, int nc)
+__device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const int * /*cbody_g*/, int nc)
 {
+    const int *cbody = L.cb;
     const int lane = lane_id(), n = L.n, lda = L.lda, nz = L.nz;
     for (int e = lane; e < n * lda; e += WAVE) L.K[e] = 0.0;
     __syncthreads();
@@ -373,13 +379,14 @@ struct StepAcc {
 template <int ND>
 __global__ void __launch_bounds__(64)
 lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const double *A_, const double *bvec_,
-                           const double *cop_, const int *cbody_, const int *ncs, int nb, int neq, int maxc,
-                           double eps, int not_improved_lim, int max_iter, double *x_out_, double *lam_,
+                           const double *cop_, const int *cbody_, const int *ncs, const int *active, int nb, int neq,
+                           int maxc, double eps, int not_improved_lim, int max_iter, double *x_out_, double *lam_,
                            double *slack_, double *nu_, int *iters, int *status, double *ws_)
 {
     constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
     DSS_DYN_LDS(double, ldsmem);
     const int sc = blockIdx.x, lane = lane_id();
+    if (active && !active[sc]) return;
     Lds L;
     carve_lds(L, ldsmem, nb, neq, maxc);
     const int nz = L.nz, n = L.n;
@@ -689,6 +696,7 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
 #pragma unroll
         for (int j = 0; j < 6; ++j) L.pbuf[6 * c + j] = cop[(size_t)(o + j) * maxc + c];
     }
+    for (int c = lane; c < nc; c += WAVE) { L.cb[c] = cbody[c]; L.cb[maxc + c] = cbody[maxc + c]; }
     if (lane < nz) L.xv[lane] = x_[(size_t)sc * nz + lane];
     else if (lane < n) L.xv[lane] = nu_[(size_t)sc * neq + lane - nz];
     __syncthreads();
@@ -783,8 +791,8 @@ size_t dss_lcp_contact_workspace_bytes(int B, int nb, int neq, int maxc, int fri
 }
 
 int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double *A, const double *bvec,
-                            const double *cop, const int *cbody, const int *nc, int B, int nb, int neq, int maxc,
-                            int fric_dirs, double eps, int not_improved_lim, int max_iter, double *x, double *lam,
+                            const double *cop, const int *cbody, const int *nc, const int *active, int B, int nb,
+                            int neq, int maxc, int fric_dirs, double eps, int not_improved_lim, int max_iter, double *x, double *lam,
                             double *slack, double *nu, int *iters, int *status, void *workspace,
                             size_t workspace_bytes, void *stream)
 {
@@ -797,11 +805,11 @@ int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_forward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
-                           cop, cbody, nc, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
+                           cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
                            status, (double *)workspace);
     else
         hipLaunchKernelGGL(lcp_contact_forward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
-                           cop, cbody, nc, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
+                           cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
                            status, (double *)workspace);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }

@@ -1,0 +1,641 @@
+// narrowphase.hip -- SDF contact detection for the batched stepper (gfx950).
+//
+// Restates FWContactHandler (sdf_physics/physics3d/contacts.py:217-272) for a batch of scenes:
+//   overlap_kernel      _overlap                         contacts.py:27-36
+//   narrowphase_kernel  _frank_wolfe                     contacts.py:39-94
+//                       _compute_contacts                contacts.py:161-214
+//                       _filter_contacts                 contacts.py:97-158
+//   compact_kernel      the order in which the callbacks append to world.contacts
+// One 256-thread workgroup owns one (scene, directed body pair a->b): the triangles of a's mesh
+// are searched against b's SDF.  Pair order is canonical (i<j, then i->j before j->i), standing
+// in for ODE's unreproducible HashSpace callback order.  Everything that the
+// reference decides over the whole candidate set of a pair (early exits of the Frank-Wolfe loop,
+// the "all penetrations <= tol" test, greedy normal clustering) is decided over the workgroup.
+// Candidate and contact lists are compacted in ascending face order with ballot prefix sums, so
+// results are deterministic and cluster seeds match the reference's.
+//
+// The reference thins each normal cluster with Qhull (3-D hull, falling back to 2-D / 1-D when the
+// points are flat).  Here: flatness tests with the same fall-back order, a gift-wrapping hull in
+// 2-D (collinear points dropped), min/max in 1-D and a supporting-plane test in 3-D.
+#include <math.h>
+
+#include "../../include/diffsdfsim_hip.h"
+#include "contact_geom.h"
+#include "wave_utils.h"
+
+namespace {
+using namespace dss;
+
+constexpr int NT = 256;
+constexpr int MAX_CPT = 8;       // candidates per thread: max_cand <= NT * MAX_CPT
+constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
+
+__device__ inline int npairs_of(int nb) { return nb * (nb - 1); }
+__device__ inline void pair_of(int dp, int nb, int &a, int &b)
+{
+    a = dp / (nb - 1);
+    const int r = dp % (nb - 1);
+    b = r < a ? r : r + 1;
+}
+
+struct BodyD {
+    BodyG<double> g;
+    int mesh, voff, nv, foff, nf;
+};
+
+__device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
+{
+    const double *ps = W.pose + ((size_t)sc * W.nb + b) * 7;
+    for (int i = 0; i < 4; ++i) o.g.q[i] = ps[i];
+    for (int i = 0; i < 3; ++i) o.g.pos[i] = ps[4 + i];
+    const double *prm = W.shape_prm + ((size_t)sc * W.nb + b) * 3;
+    make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm);
+    o.mesh = W.mesh_id[(size_t)sc * W.nb + b];
+    o.voff = W.mesh_voff[o.mesh]; o.nv = W.mesh_nv[o.mesh];
+    o.foff = W.mesh_foff[o.mesh]; o.nf = W.mesh_nf[o.mesh];
+}
+
+// vertex of body `a` (body frame) -> frame of body b, in the reference's order of operations:
+// world = R_a v + x_a (get_surface, bodies.py:716-719), then R_b^-1 (world - x_b) (contacts.py:42)
+__device__ inline void to_frame(const BodyG<double> &a, const BodyG<double> &b, const double *v, double *o)
+{
+    double w[3], r[3];
+    quat_apply(a.q, v, w);
+    for (int i = 0; i < 3; ++i) r[i] = (w[i] + a.pos[i]) - b.pos[i];
+    quat_apply_inv(b.q, r, o);
+}
+
+// ---- _overlap ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
+{
+    const int nup = W.nb * (W.nb - 1) / 2;
+    const int sc = blockIdx.x / nup, up = blockIdx.x % nup, tid = threadIdx.x;
+    if (!W.active[sc]) return;
+    int i = 0, rem = up;
+    while (rem >= W.nb - 1 - i) { rem -= W.nb - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    int *flag = W.ovl + ((size_t)sc * W.nb + i) * W.nb + j;
+    if (W.no_contact[i * W.nb + j]) { if (tid == 0) *flag = 0; return; }
+    BodyD A, Bd;
+    load_body(W, sc, i, A);
+    load_body(W, sc, j, Bd);
+    int ok = 1;
+    for (int dir = 0; dir < 2 && ok; ++dir) {
+        const BodyD &src = dir ? Bd : A, &dst = dir ? A : Bd;
+        const double s = dst.g.shape.scale;
+        int found = 0;
+        for (int base = 0; base < src.nv && !found; base += NT) {
+            int hit = 0;
+            const int v = base + tid;
+            if (v < src.nv) {
+                double p[3];
+                to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
+                hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+            }
+            found = __syncthreads_or(hit);
+        }
+        ok = found;
+    }
+    if (tid == 0) *flag = ok;
+}
+
+// ---- workgroup scratch ------------------------------------------------------------------------
+struct Scratch {
+    int wave_tot[NT / 64];
+    int red_i[NT];
+    double red_d[NT];
+    double hp[3 * 1024];   // cluster points for the hull
+    int hidx[1024];
+    unsigned char hflag[1024];
+};
+
+// ordered compaction: returns this thread's output slot (or -1) and updates the running count
+__device__ inline int compact_slot(int flag, int &count, Scratch &S)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int pre = __popcll(m & ((1ull << lane) - 1ull)), tot = __popcll(m);
+    if (lane == 0) S.wave_tot[wv] = tot;
+    __syncthreads();
+    int off = count, all = 0;
+    for (int w = 0; w < NT / 64; ++w) { if (w < wv) off += S.wave_tot[w]; all += S.wave_tot[w]; }
+    __syncthreads();
+    count += all;
+    return flag ? off + pre : -1;
+}
+
+// block arg-min over (key, index) with lowest index on ties; returns the index (or -1 if none valid)
+__device__ inline int block_argmin(double key, int idx, Scratch &S)
+{
+    const int tid = threadIdx.x;
+    S.red_d[tid] = key; S.red_i[tid] = idx;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ok = S.red_d[tid + s]; const int oi = S.red_i[tid + s];
+            const int mi = S.red_i[tid];
+            if (oi >= 0 && (mi < 0 || ok < S.red_d[tid] || (ok == S.red_d[tid] && oi < mi))) { S.red_d[tid] = ok; S.red_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const int r = S.red_i[0];
+    __syncthreads();
+    return r;
+}
+__device__ inline double block_max(double v, Scratch &S)
+{
+    const int tid = threadIdx.x;
+    S.red_d[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] = fmax(S.red_d[tid], S.red_d[tid + s]); __syncthreads(); }
+    const double r = S.red_d[0];
+    __syncthreads();
+    return r;
+}
+__device__ inline double block_sum(double v, Scratch &S)
+{
+    const int tid = threadIdx.x;
+    S.red_d[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] += S.red_d[tid + s]; __syncthreads(); }
+    const double r = S.red_d[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- hull of one normal cluster (points in S.hp, m of them); marks S.hflag ---------------------
+// Mirrors the fall-back ladder of contacts.py:126-152: 3-D hull; if Qhull would reject the input as
+// flat drop the coordinate of least variance and retry in 2-D; then 1-D min/max.
+__device__ void cluster_hull(Scratch &S, int m, double eps)
+{
+    const int tid = threadIdx.x;
+    for (int k = tid; k < m; k += NT) S.hflag[k] = 0;
+    __syncthreads();
+    if (m == 1) { if (tid == 0) S.hflag[0] = 1; __syncthreads(); return; }
+    // per-coordinate mean / unbiased variance (torch.var)
+    double mean[3], var[3], amax = 0.0;
+    for (int d = 0; d < 3; ++d) {
+        double acc = 0.0, mx = 0.0;
+        for (int k = tid; k < m; k += NT) { acc += S.hp[3 * k + d]; mx = fmax(mx, fabs(S.hp[3 * k + d])); }
+        mean[d] = block_sum(acc, S) / m;
+        amax = fmax(amax, block_max(mx, S));
+        acc = 0.0;
+        for (int k = tid; k < m; k += NT) { const double t = S.hp[3 * k + d] - mean[d]; acc += t * t; }
+        var[d] = block_sum(acc, S) / (m - 1);
+    }
+    const double tolf = 1e-12 * (1.0 + amax);
+    // farthest point B from A = point 0, then C farthest from line AB
+    const double *A = S.hp;
+    double key = -1.0; int ki = -1;
+    for (int k = tid; k < m; k += NT) {
+        const double d0 = S.hp[3 * k] - A[0], d1 = S.hp[3 * k + 1] - A[1], d2 = S.hp[3 * k + 2] - A[2];
+        const double dd = d0 * d0 + d1 * d1 + d2 * d2;
+        if (dd > key) { key = dd; ki = k; }
+    }
+    const int iB = block_argmin(-key, ki, S);
+    double ab[3] = {S.hp[3 * iB] - A[0], S.hp[3 * iB + 1] - A[1], S.hp[3 * iB + 2] - A[2]};
+    const double lab = sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
+    bool flat3 = (m < 4) || !(lab > tolf), line = !(lab > tolf);
+    double nrm[3] = {0, 0, 0};
+    if (!line) {
+        key = -1.0; ki = -1;
+        for (int k = tid; k < m; k += NT) {
+            const double d[3] = {S.hp[3 * k] - A[0], S.hp[3 * k + 1] - A[1], S.hp[3 * k + 2] - A[2]};
+            double c[3];
+            cross(ab, d, c);
+            const double dd = (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            if (dd > key) { key = dd; ki = k; }
+        }
+        const int iC = block_argmin(-key, ki, S);
+        const double ac[3] = {S.hp[3 * iC] - A[0], S.hp[3 * iC + 1] - A[1], S.hp[3 * iC + 2] - A[2]};
+        cross(ab, ac, nrm);
+        const double ln = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        if (!(ln / lab > tolf)) { line = true; flat3 = true; }
+        else {
+            for (int d = 0; d < 3; ++d) nrm[d] /= ln;
+            double mx = 0.0;
+            for (int k = tid; k < m; k += NT)
+                mx = fmax(mx, fabs(nrm[0] * (S.hp[3 * k] - A[0]) + nrm[1] * (S.hp[3 * k + 1] - A[1]) + nrm[2] * (S.hp[3 * k + 2] - A[2])));
+            if (!(block_max(mx, S) > tolf)) flat3 = true;
+        }
+    }
+    if (!flat3) {
+        if (m > HULL3_MAX) {  // beyond the brute-force limit: keep every point (superset of the hull)
+            for (int k = tid; k < m; k += NT) S.hflag[k] = 1;
+            __syncthreads();
+            return;
+        }
+        // supporting-plane test over all triples
+        const int ntri = m * m * m;
+        for (int e = tid; e < ntri; e += NT) {
+            const int i = e / (m * m), j = (e / m) % m, k = e % m;
+            if (!(i < j && j < k)) continue;
+            const double u[3] = {S.hp[3 * j] - S.hp[3 * i], S.hp[3 * j + 1] - S.hp[3 * i + 1], S.hp[3 * j + 2] - S.hp[3 * i + 2]};
+            const double v[3] = {S.hp[3 * k] - S.hp[3 * i], S.hp[3 * k + 1] - S.hp[3 * i + 1], S.hp[3 * k + 2] - S.hp[3 * i + 2]};
+            double n[3];
+            cross(u, v, n);
+            const double ln = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(ln > 1e-14 * (1.0 + amax) * (1.0 + amax))) continue;
+            int pos = 0, neg = 0;
+            for (int q = 0; q < m; ++q) {
+                const double sd = (n[0] * (S.hp[3 * q] - S.hp[3 * i]) + n[1] * (S.hp[3 * q + 1] - S.hp[3 * i + 1]) + n[2] * (S.hp[3 * q + 2] - S.hp[3 * i + 2])) / ln;
+                pos |= sd > tolf; neg |= sd < -tolf;
+            }
+            if (!(pos && neg)) { S.hflag[i] = 1; S.hflag[j] = 1; S.hflag[k] = 1; }
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- 2-D: drop the coordinate of least variance (first index on ties, torch.argmin) ---------
+    int drop = 0;
+    for (int d = 1; d < 3; ++d) if (var[d] < var[drop]) drop = d;
+    if (var[0] != var[0]) drop = 0;
+    const int c0 = drop == 0 ? 1 : 0, c1 = drop == 2 ? 1 : 2;
+    bool collinear = (m < 3);
+    int iS = -1;
+    if (!collinear) {
+        // start: lexicographic minimum
+        double k0 = INFINITY; int k0i = -1;
+        for (int k = tid; k < m; k += NT) if (S.hp[3 * k + c0] < k0) { k0 = S.hp[3 * k + c0]; k0i = k; }
+        const int i0 = block_argmin(k0, k0i, S);
+        const double x0 = S.hp[3 * i0 + c0];
+        k0 = INFINITY; k0i = -1;
+        for (int k = tid; k < m; k += NT) if (S.hp[3 * k + c0] == x0 && S.hp[3 * k + c1] < k0) { k0 = S.hp[3 * k + c1]; k0i = k; }
+        iS = block_argmin(k0, k0i, S);
+        // collinearity: farthest point from the start, then max distance to that line
+        key = -1.0; ki = -1;
+        for (int k = tid; k < m; k += NT) {
+            const double d0 = S.hp[3 * k + c0] - S.hp[3 * iS + c0], d1 = S.hp[3 * k + c1] - S.hp[3 * iS + c1];
+            if (d0 * d0 + d1 * d1 > key) { key = d0 * d0 + d1 * d1; ki = k; }
+        }
+        const int iF = block_argmin(-key, ki, S);
+        const double e0 = S.hp[3 * iF + c0] - S.hp[3 * iS + c0], e1 = S.hp[3 * iF + c1] - S.hp[3 * iS + c1];
+        const double le = sqrt(e0 * e0 + e1 * e1);
+        if (!(le > tolf)) collinear = true;
+        else {
+            double mx = 0.0;
+            for (int k = tid; k < m; k += NT)
+                mx = fmax(mx, fabs(e0 * (S.hp[3 * k + c1] - S.hp[3 * iS + c1]) - e1 * (S.hp[3 * k + c0] - S.hp[3 * iS + c0])) / le);
+            if (!(block_max(mx, S) > tolf)) collinear = true;
+        }
+    }
+    if (!collinear) {
+        // gift wrapping, counter-clockwise; collinear candidates: the farthest wins (interior ones dropped)
+        int cur = iS;
+        for (int step = 0; step < m; ++step) {
+            if (tid == 0) S.hflag[cur] = 1;
+            const double cx = S.hp[3 * cur + c0], cy = S.hp[3 * cur + c1];
+            int best = -1; double bx = 0, by = 0;
+            for (int k = tid; k < m; k += NT) {
+                const double qx = S.hp[3 * k + c0] - cx, qy = S.hp[3 * k + c1] - cy;
+                const double lq = qx * qx + qy * qy;
+                if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
+                if (best < 0) { best = k; bx = qx; by = qy; continue; }
+                const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
+                if (cr < -1e-9 * sqrt(lb * lq) || (fabs(cr) <= 1e-9 * sqrt(lb * lq) && lq > lb)) { best = k; bx = qx; by = qy; }
+            }
+            S.red_i[tid] = best;
+            __syncthreads();
+            for (int s = NT / 2; s > 0; s >>= 1) {
+                if (tid < s) {
+                    const int a = S.red_i[tid], b = S.red_i[tid + s];
+                    if (b >= 0) {
+                        if (a < 0) S.red_i[tid] = b;
+                        else {
+                            const double ax = S.hp[3 * a + c0] - cx, ay = S.hp[3 * a + c1] - cy;
+                            const double qx = S.hp[3 * b + c0] - cx, qy = S.hp[3 * b + c1] - cy;
+                            const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
+                            if (cr < -1e-9 * sqrt(la * lq) || (fabs(cr) <= 1e-9 * sqrt(la * lq) && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            const int nxt = S.red_i[0];
+            __syncthreads();
+            if (nxt < 0 || nxt == iS) break;
+            cur = nxt;
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- 1-D: drop the next least-variance coordinate, keep min (and max if the spread > eps) ---
+    const int keep = (var[c1] < var[c0]) ? c0 : c1;  // argmin over the remaining two drops the smaller
+    double kmin = INFINITY, kmax = -INFINITY; int imin = -1, imax = -1;
+    for (int k = tid; k < m; k += NT) {
+        const double v = S.hp[3 * k + keep];
+        if (v < kmin) { kmin = v; imin = k; }
+        if (v > kmax) { kmax = v; imax = k; }
+    }
+    const int gmin = block_argmin(kmin, imin, S), gmax = block_argmin(-kmax, imax, S);
+    if (tid == 0) {
+        S.hflag[gmin] = 1;
+        if (S.hp[3 * gmax + keep] - S.hp[3 * gmin + keep] > eps) S.hflag[gmax] = 1;
+    }
+    __syncthreads();
+}
+
+// ---- the narrow phase -------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
+{
+    __shared__ Scratch S;
+    const int np = npairs_of(W.nb);
+    const int sc = blockIdx.x / np, dp = blockIdx.x % np, tid = threadIdx.x;
+    if (!W.active[sc]) return;
+    int a, b;
+    pair_of(dp, W.nb, a, b);
+    int *pc_count = W.pc_count + (size_t)sc * np + dp;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    if (W.no_contact[a * W.nb + b] || !W.ovl[((size_t)sc * W.nb + lo) * W.nb + hi]) { if (tid == 0) *pc_count = 0; return; }
+    BodyD A, Bd;
+    load_body(W, sc, a, A);
+    load_body(W, sc, b, Bd);
+    const int MC = W.max_cand;
+    int *cface = W.cand_face + ((size_t)sc * np + dp) * 2 * MC, *kface = cface + MC;
+    int *cstate = W.cand_state + ((size_t)sc * np + dp) * MC;
+    double *cb = W.cand_buf + ((size_t)sc * np + dp) * DSS_CAND_FIELDS * MC;
+#define CB(f, k) cb[(size_t)(f) * MC + (k)]
+    const double sB = Bd.g.shape.scale;
+
+    // composite transform for the cheap centroid cull (pose-invariant centroids / radii)
+    double Ra[9], Rb[9], R12[9], t12[3];
+    quat_to_mat(A.g.q, Ra);
+    quat_to_mat(Bd.g.q, Rb);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R12[3 * i + j] = Rb[i] * Ra[j] + Rb[3 + i] * Ra[3 + j] + Rb[6 + i] * Ra[6 + j];
+        t12[i] = Rb[i] * (A.g.pos[0] - Bd.g.pos[0]) + Rb[3 + i] * (A.g.pos[1] - Bd.g.pos[1]) + Rb[6 + i] * (A.g.pos[2] - Bd.g.pos[2]);
+    }
+
+    // ---- 1. candidate faces (contacts.py:44-52) in ascending face order ------------------------
+    int ncand = 0, over = 0;
+    for (int base = 0; base < A.nf; base += NT) {
+        const int f = base + tid;
+        int flag = 0;
+        double pqr[3][3];
+        if (f < A.nf) {
+            const double *c = W.fcent + (size_t)(A.foff + f) * 3;
+            double cb2[3];
+            for (int i = 0; i < 3; ++i) cb2[i] = R12[3 * i] * c[0] + R12[3 * i + 1] * c[1] + R12[3 * i + 2] * c[2] + t12[i];
+            const double lim = sB + 1e-9 * (1.0 + sB);
+            if (fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim) {
+                const int *fv = W.faces + (size_t)(A.foff + f) * 3;
+                double x[3] = {0, 0, 0};
+                for (int k = 0; k < 3; ++k) {
+                    to_frame(A.g, Bd.g, W.verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
+                    for (int i = 0; i < 3; ++i) x[i] += pqr[k][i];
+                }
+                for (int i = 0; i < 3; ++i) x[i] /= 3.0;
+                double phi, g[3], rad = 0.0;
+                query_sdf(Bd.g.shape, x, phi, g, true);
+                for (int k = 0; k < 3; ++k) {
+                    const double d[3] = {x[0] - pqr[k][0], x[1] - pqr[k][1], x[2] - pqr[k][2]};
+                    const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    if (r > rad) rad = r;
+                }
+                const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                flag = (phi < rad + W.eps) && (gn > 1e-12);
+            }
+        }
+        if (!__syncthreads_or(flag)) continue;
+        const int slot = compact_slot(flag, ncand, S);
+        if (slot >= 0 && slot < MC) {
+            cface[slot] = f;
+            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
+        }
+        if (ncand > MC) { over = 1; ncand = MC; }
+    }
+    if (ncand == 0) { if (tid == 0) *pc_count = 0; return; }
+    __syncthreads();
+
+    // ---- 2. Frank-Wolfe (contacts.py:57-82) -----------------------------------------------------
+    for (int k = tid; k < ncand; k += NT) {
+        double best = INFINITY; int bi = 0;
+        for (int v = 0; v < 3; ++v) {
+            const double p[3] = {CB(3 * v, k), CB(3 * v + 1, k), CB(3 * v + 2, k)};
+            double phi, g[3];
+            query_sdf(Bd.g.shape, p, phi, g, false);
+            if (phi < best) { best = phi; bi = v; }
+        }
+        for (int i = 0; i < 3; ++i) { CB(9 + i, k) = CB(3 * bi + i, k); CB(12 + i, k) = (i == bi) ? 1.0 : 0.0; }
+    }
+    __syncthreads();
+    for (int iter = 0; iter < 32; ++iter) {
+        // NOTE the reference forms gamma as python_float * bool_tensor (contacts.py:72-73), which torch
+        // promotes to float32: the step sizes, and 1 - gamma, are float32-rounded.  Replicated bit for bit.
+        float gam[MAX_CPT]; int ind[MAX_CPT];
+        int any_pen = 0, all_zero = 1, q = 0;
+        for (int k = tid; k < ncand; k += NT, ++q) {
+            const double x[3] = {CB(9, k), CB(10, k), CB(11, k)};
+            double phi, g[3];
+            query_sdf(Bd.g.shape, x, phi, g, true);
+            double bestd = INFINITY; int bi = 0;
+            for (int v = 0; v < 3; ++v) {
+                const double d = CB(3 * v, k) * g[0] + CB(3 * v + 1, k) * g[1] + CB(3 * v + 2, k) * g[2];
+                if (d < bestd) { bestd = d; bi = v; }
+            }
+            const double impr = (x[0] - CB(3 * bi, k)) * g[0] + (x[1] - CB(3 * bi + 1, k)) * g[1] + (x[2] - CB(3 * bi + 2, k)) * g[2];
+            const float gm = (fabs(impr) > W.tol) ? (float)(2.0 / (iter + 2.0)) : 0.0f;
+            gam[q] = gm; ind[q] = bi;
+            if (gm != 0.0f) all_zero = 0;
+            if (phi < -W.tol) any_pen = 1;
+        }
+        const int stop_a = __syncthreads_and(all_zero), stop_b = __syncthreads_or(any_pen);
+        if (stop_a || stop_b) break;
+        q = 0;
+        for (int k = tid; k < ncand; k += NT, ++q) {
+            const double gm = (double)gam[q], om = (double)(1.0f - gam[q]);
+            const int bi = ind[q];
+            for (int i = 0; i < 3; ++i) {
+                CB(9 + i, k) = om * CB(9 + i, k) + gm * CB(3 * bi + i, k);
+                CB(12 + i, k) *= om;
+            }
+            CB(12 + bi, k) += gm;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) -------------------
+    double qrel[4];
+    {
+        double qbi[4];
+        quat_inv(Bd.g.q, qbi);
+        quat_mul(qbi, A.g.q, qrel);
+    }
+    int ncon = 0;
+    for (int base = 0; base < ncand; base += NT) {
+        const int k = base + tid;
+        int flag = 0;
+        double abc[3] = {0, 0, 0};
+        if (k < ncand) {
+            const int *fv = W.faces + (size_t)(A.foff + cface[k]) * 3;
+            double xb1[3] = {0, 0, 0};
+            for (int v = 0; v < 3; ++v) {
+                abc[v] = CB(12 + v, k);
+                const double *vp = W.verts + (size_t)(A.voff + fv[v]) * 3;
+                for (int i = 0; i < 3; ++i) xb1[i] += vp[i] * abc[v];
+            }
+            double phi1, g1[3], gr[3], x[3], phi2, g2[3];
+            query_sdf(A.g.shape, xb1, phi1, g1, true);
+            quat_apply(qrel, g1, gr);
+            for (int i = 0; i < 3; ++i) x[i] = CB(9 + i, k) - phi1 * gr[i];
+            query_sdf(Bd.g.shape, x, phi2, g2, false);
+            flag = phi2 <= W.eps;
+        }
+        if (!__syncthreads_or(flag)) continue;
+        const int slot = compact_slot(flag, ncon, S);
+        if (slot >= 0) { kface[slot] = cface[k]; for (int i = 0; i < 3; ++i) CB(15 + i, slot) = abc[i]; }
+    }
+    if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) W.overflow[sc] = 1; } return; }
+    __syncthreads();
+
+    // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
+    int bad = 0;
+    for (int k = tid; k < ncon; k += NT) {
+        const int *fv = W.faces + (size_t)(A.foff + kface[k]) * 3;
+        double tri[3][3], n[3], p1[3], p2[3], pen;
+        for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
+        const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
+        contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
+        for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; }
+        CB(24, k) = pen;
+        if (!(pen <= W.tol)) bad = 1;
+    }
+    if (__syncthreads_or(bad)) {
+        if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
+        return;
+    }
+
+    // ---- 5. filter: greedy normal clusters, hull of each (contacts.py:97-158) -------------------
+    int nkeep = 0;
+    if (ncon <= 1) {
+        if (tid == 0) cstate[0] = -2;  // kept
+        nkeep = ncon;
+    } else {
+        for (int k = tid; k < ncon; k += NT) {
+            const double nn = sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
+            cstate[k] = nn > 1e-12 ? 0 : -1;
+        }
+        __syncthreads();
+        for (int cl = 1; cl <= ncon; ++cl) {
+            int mine = -1;
+            for (int k = tid; k < ncon; k += NT) if (cstate[k] == 0) { mine = k; break; }
+            const int seed = block_argmin(mine >= 0 ? (double)mine : INFINITY, mine, S);
+            if (seed < 0) break;
+            const double sn[3] = {CB(18, seed), CB(19, seed), CB(20, seed)};
+            // gather the cluster (ascending) into the hull scratch
+            int m = 0;
+            for (int base = 0; base < ncon; base += NT) {
+                const int k = base + tid;
+                int in = 0;
+                if (k < ncon && cstate[k] == 0) {
+                    const double d = fmin(CB(18, k) * sn[0] + CB(19, k) * sn[1] + CB(20, k) * sn[2], 1.0);
+                    in = acos(d) < 1e-2;
+                }
+                const int slot = compact_slot(in, m, S);
+                if (slot >= 0) {
+                    cstate[k] = cl;
+                    if (slot < 1024) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = CB(21 + i, k); }
+                }
+            }
+            __syncthreads();
+            if (m > 1024) { over = 1; m = 1024; }
+            cluster_hull(S, m, W.eps);
+            for (int j = tid; j < m; j += NT) if (S.hflag[j]) cstate[S.hidx[j]] = -2;
+            __syncthreads();
+        }
+        for (int k = tid; k < ncon; k += NT) nkeep += (cstate[k] == -2);
+        nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
+    }
+
+    // ---- 6. final geometry of the kept contacts, in ascending face order --------------------------
+    // (the reference emits cluster by cluster in Qhull's vertex order, which is implementation
+    //  defined; contact sets of a pair are compared as sets)
+    int nout = 0;
+    const int MP = W.max_pc;
+    int *pf = W.pc_face + ((size_t)sc * np + dp) * MP;
+    double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
+    if (ncon <= 1) {
+        if (tid == 0) {
+            const int *fv = W.faces + (size_t)(A.foff + kface[0]) * 3;
+            double tri[3][3], n[3], p1[3], p2[3], pen;
+            for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
+            const double abc[3] = {CB(15, 0), CB(16, 0), CB(17, 0)};
+            contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
+            pf[0] = kface[0];
+            for (int i = 0; i < 3; ++i) { pabc[(size_t)i * MP] = abc[i]; pg[(size_t)i * MP] = n[i]; pg[(size_t)(3 + i) * MP] = p1[i]; pg[(size_t)(6 + i) * MP] = p2[i]; }
+            pg[(size_t)9 * MP] = pen;
+        }
+        nout = 1;
+    } else {
+        for (int base = 0; base < ncon; base += NT) {
+            const int k = base + tid;
+            const int flag = (k < ncon) && cstate[k] == -2;
+            if (!__syncthreads_or(flag)) continue;
+            const int slot = compact_slot(flag, nout, S);
+            if (slot >= 0 && slot < MP) {
+                const int *fv = W.faces + (size_t)(A.foff + kface[k]) * 3;
+                double tri[3][3], n[3], p1[3], p2[3], pen;
+                for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
+                const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
+                contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
+                pf[slot] = kface[k];
+                for (int i = 0; i < 3; ++i) {
+                    pabc[(size_t)i * MP + slot] = abc[i];
+                    pg[(size_t)i * MP + slot] = n[i]; pg[(size_t)(3 + i) * MP + slot] = p1[i]; pg[(size_t)(6 + i) * MP + slot] = p2[i];
+                }
+                pg[(size_t)9 * MP + slot] = pen;
+            }
+        }
+        if (nout > MP) { over = 1; nout = MP; }
+    }
+    if (tid == 0) { *pc_count = nout; if (over) W.overflow[sc] = 1; }
+#undef CB
+}
+
+// ---- gather the per-pair lists into the scene's contact list in callback order ------------------
+__global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *nc_out, int *body_out, int *face_out,
+                                                               double *abc_out, double *geom_out)
+{
+    const int sc = blockIdx.x, lane = threadIdx.x, np = npairs_of(W.nb), MP = W.max_pc, MX = W.maxc;
+    if (!W.active[sc]) return;
+    int off = 0;
+    for (int i = 0; i < W.nb; ++i)
+        for (int j = i + 1; j < W.nb; ++j)
+            for (int dir = 0; dir < 2; ++dir) {
+                const int a = dir ? j : i, b = dir ? i : j;
+                const int dp = a * (W.nb - 1) + (b < a ? b : b - 1);
+                const int cnt = W.pc_count[(size_t)sc * np + dp];
+                const int *pf = W.pc_face + ((size_t)sc * np + dp) * MP;
+                const double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
+                for (int k = lane; k < cnt; k += 64) {
+                    const int o = off + k;
+                    if (o >= MX) continue;
+                    body_out[(size_t)sc * 2 * MX + o] = a;
+                    body_out[(size_t)sc * 2 * MX + MX + o] = b;
+                    face_out[(size_t)sc * MX + o] = pf[k];
+                    for (int f = 0; f < 3; ++f) abc_out[((size_t)sc * 3 + f) * MX + o] = pabc[(size_t)f * MP + k];
+                    for (int f = 0; f < 10; ++f) geom_out[((size_t)sc * 10 + f) * MX + o] = pg[(size_t)f * MP + k];
+                }
+                off += cnt;
+            }
+    if (lane == 0) {
+        if (off > MX) { W.overflow[sc] = 1; off = MX; }
+        nc_out[sc] = off;
+    }
+}
+
+}  // namespace
+
+namespace dss {
+// enqueue detection at the current pose; results land in (nc_out, body_out, ...)
+int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
+                         double *geom_out, hipStream_t stream)
+{
+    if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
+    const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
+    hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
+    hipLaunchKernelGGL(narrowphase_kernel, dim3(W.B * np), dim3(NT), 0, stream, W);
+    hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+}  // namespace dss

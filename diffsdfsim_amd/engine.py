@@ -1,0 +1,159 @@
+"""BatchEngine -- host driver of the batched stepper (C ABI section B3).
+
+Owns the device arrays of a batch of B independent scenes (struct-of-arrays over the scene axis),
+binds them into a ``DssWorld`` descriptor and runs the reference's ``World.step`` loop
+(lcp_physics/physics/world.py:119-139, 241-379) for all scenes in lock step: every *attempt*
+(solve -> integrate -> detect -> accept or halve dt) is one ``dss_step_attempt`` call; scenes that
+reach the end of the outer step go inactive, the loop ends when none is active.  The only
+host<->device traffic per attempt is the 4-byte active-scene counter.
+
+Storage goes through a small backend object (``TorchBackend``: torch tensors on a HIP device, the
+product path).  tests/emu supplies a numpy backend bound to the CPU emulation build of the same
+kernels for logic tests in the GPU-less build container; nothing in this package refers to it.
+"""
+import ctypes
+
+import numpy as np
+
+from . import world_abi as abi
+
+
+class TorchBackend:
+    """Device arrays as torch tensors on a HIP device; no CPU fallback."""
+
+    def __init__(self, device="cuda"):
+        import torch
+        from . import _lib
+        self.torch = torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _lib.HipLibraryError("BatchEngine needs a HIP device (got %s); there is no CPU fallback" % device)
+        self.lib = _lib.lib()
+        self._lib = _lib
+
+    def zeros(self, shape, dtype):
+        t = {np.float64: self.torch.float64, np.int32: self.torch.int32, np.uint8: self.torch.uint8}[dtype]
+        return self.torch.zeros(shape, dtype=t, device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a)).to(self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def read_int(self, t):
+        return int(t.item())
+
+
+def mesh_table(meshes):
+    """Concatenate (verts, faces) meshes; precompute pose-invariant face centroids and radii."""
+    voff, nv, foff, nf, V, F, C, R = [], [], [], [], [], [], [], []
+    vo = fo = 0
+    for verts, faces in meshes:
+        verts = np.asarray(verts, np.float64); faces = np.asarray(faces, np.int64)
+        voff.append(vo); nv.append(len(verts)); foff.append(fo); nf.append(len(faces))
+        tri = verts[faces]
+        cen = tri.mean(axis=1)
+        rad = np.linalg.norm(cen[:, None, :] - tri, axis=2).max(axis=1)
+        V.append(verts); F.append(faces.astype(np.int32)); C.append(cen); R.append(rad)
+        vo += len(verts); fo += len(faces)
+    i32 = lambda x: np.asarray(x, np.int32)
+    return dict(mesh_voff=i32(voff), mesh_nv=i32(nv), mesh_foff=i32(foff), mesh_nf=i32(nf),
+                verts=np.concatenate(V), faces=np.concatenate(F), fcent=np.concatenate(C), frad=np.concatenate(R))
+
+
+class BatchEngine:
+    def __init__(self, spec, dt=1.0 / 30, eps=1e-3, tol=1e-8, fric_dirs=8, maxc=64, max_cand=1024, max_pc=32,
+                 max_sub=0, strict_no_pen=True, toc_diff=True, lcp_max_iter=10, backend=None):
+        """``spec``: numpy arrays pose [B,nb,7], vel [B,nb,6], mass, inertia [B,nb,3,3], restitution, fric,
+        fext [B,nb,6], shape_type, shape_prm [B,nb,3], mesh_id [B,nb], meshes [(verts, faces)...],
+        no_contact [nb,nb] (optional), Je [B,neq,6nb] (optional)."""
+        self.be = backend if backend is not None else TorchBackend()
+        pose = np.asarray(spec["pose"], np.float64)
+        B, nb = pose.shape[:2]
+        Je = np.asarray(spec.get("Je", np.zeros((B, 0, 6 * nb))), np.float64)
+        neq = Je.shape[1]
+        self.B, self.nb, self.neq, self.maxc, self.fd = B, nb, neq, maxc, fric_dirs
+        self.max_sub = max_sub
+        mt = mesh_table(spec["meshes"])
+        shapes = abi.array_shapes(B, nb, neq, maxc, fric_dirs, max_cand, max_pc, max_sub, len(spec["meshes"]),
+                                  len(mt["verts"]), len(mt["faces"]))
+        kinds = dict(abi.FIELDS)
+        self.arr = {}
+        for name, shp in shapes.items():
+            self.arr[name] = self.be.zeros(shp, abi.NP_DTYPE[kinds[name]])
+        host = dict(mt)
+        host.update(pose=pose, vel=spec["vel"], mass=spec["mass"], inertia=np.asarray(spec["inertia"]).reshape(B, nb, 9),
+                    restitution=spec["restitution"], fric=spec["fric"], fext=spec["fext"], shape_type=spec["shape_type"],
+                    shape_prm=spec["shape_prm"], mesh_id=spec["mesh_id"])
+        host["no_contact"] = np.asarray(spec.get("no_contact", np.zeros((nb, nb))), np.uint8)
+        if neq:
+            host["Je"] = Je
+        for name, a in host.items():
+            a = np.ascontiguousarray(np.asarray(a, abi.NP_DTYPE[kinds[name]]).reshape(shapes[name]))
+            self.arr[name] = self.be.from_numpy(a)
+        W = abi.DssWorld()
+        W.B, W.nb, W.neq, W.maxc, W.fric_dirs = B, nb, neq, maxc, fric_dirs
+        W.max_cand, W.max_pc, W.nmesh = max_cand, max_pc, len(spec["meshes"])
+        W.strict_no_pen, W.toc_diff, W.lcp_max_iter = int(strict_no_pen), int(toc_diff), lcp_max_iter
+        W.eps, W.tol, W.dt = eps, tol, dt
+        W.max_sub = max_sub
+        for name, kind in abi.FIELDS:
+            if kind.startswith("p"):
+                setattr(W, name, self.be.ptr(self.arr[name]) if name in self.arr else None)
+        self.W = W
+        L = self.be.lib
+        L.dss_world_sizeof.restype = ctypes.c_size_t
+        if L.dss_world_sizeof() != ctypes.sizeof(abi.DssWorld):
+            raise RuntimeError("DssWorld layout mismatch: library %d bytes, python mirror %d bytes"
+                               % (L.dss_world_sizeof(), ctypes.sizeof(abi.DssWorld)))
+        L.dss_lcp_contact_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = L.dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fric_dirs)
+        self.lcp_ws = self.be.zeros((nbytes,), np.uint8)
+        self.lcp_ws_bytes = nbytes
+        self.attempts = 0
+        # World.__init__ (world.py:93-100): initial contacts + interpenetration check
+        self._set_active(1)
+        self._check(L.dss_find_contacts(ctypes.byref(W), self.be.stream()), "dss_find_contacts")
+        self._set_active(0)
+        if strict_no_pen:
+            nc = self.get("nc")
+            pen = self.get("c_geom")[:, 9, :]
+            for s in range(B):
+                if (pen[s, :nc[s]] > tol).any():
+                    raise AssertionError("Interpenetration at start (scene %d)" % s)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with code %d" % (what, rc))
+
+    def _set_active(self, v):
+        a = self.arr["active"]
+        a[...] = v
+
+    def get(self, name):
+        return self.be.to_numpy(self.arr[name])
+
+    # -- stepping --------------------------------------------------------------------------------
+    def step(self, max_attempts=4096):
+        """One outer step of length dt for every scene (World.step(fixed_dt=True))."""
+        L, W = self.be.lib, self.W
+        self._check(L.dss_step_begin(ctypes.byref(W), self.be.stream()), "dss_step_begin")
+        n = self.B
+        k = 0
+        while n > 0:
+            self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
+                                           ctypes.c_size_t(self.lcp_ws_bytes), self.be.stream()), "dss_step_attempt")
+            n = self.be.read_int(self.arr["n_active"])
+            k += 1
+            if k > max_attempts:
+                raise RuntimeError("step did not finish within %d attempts" % max_attempts)
+        self.attempts += k
+        return k

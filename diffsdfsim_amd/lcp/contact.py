@@ -15,7 +15,7 @@ def _setup(L):
 
 
 def lcp_contact_forward(Mblk, pvec, A, bvec, cop, cbody, nc, fric_dirs, eps=1e-12, not_improved_lim=3, max_iter=10,
-                        workspace=None):
+                        workspace=None, active=None):
     """-> x [B,nz], lam [B,NR,maxc], slack [B,NR,maxc], nu [B,neq], iters [B], status [B]."""
     _lib.require_device(Mblk, pvec, cop, cbody, nc)
     L = _lib.lib()
@@ -36,7 +36,7 @@ def lcp_contact_forward(Mblk, pvec, A, bvec, cop, cbody, nc, fric_dirs, eps=1e-1
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = L.dss_lcp_contact_forward(_lib.ptr(Mblk), _lib.ptr(pvec), _lib.ptr(A), _lib.ptr(bvec), _lib.ptr(cop),
-                                   _lib.ptr(cbody), _lib.ptr(nc), B, nb, neq, maxc, fric_dirs, ctypes.c_double(eps),
+                                   _lib.ptr(cbody), _lib.ptr(nc), _lib.ptr(active), B, nb, neq, maxc, fric_dirs, ctypes.c_double(eps),
                                    int(not_improved_lim), int(max_iter), _lib.ptr(x), _lib.ptr(lam), _lib.ptr(slack),
                                    _lib.ptr(nu), _lib.ptr(iters), _lib.ptr(status), _lib.ptr(workspace),
                                    ctypes.c_size_t(workspace.numel()), _lib.stream_ptr(dev))

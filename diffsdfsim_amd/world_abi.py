@@ -1,0 +1,82 @@
+"""ctypes mirror of ``DssWorld`` (include/diffsdfsim_hip.h, section B3) and array allocation.
+
+The field order below IS the struct layout; ``dss_world_sizeof()`` is checked against it when the
+world is first bound to the library, so a mismatch fails loudly instead of corrupting memory.
+"""
+import ctypes
+
+import numpy as np
+
+CAND_FIELDS = 28
+SHAPE_BOX, SHAPE_SPHERE = 0, 1
+
+_I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+# (name, kind) kind: 'i' int scalar, 'd' double scalar, 'pd' double*, 'pi' int*, 'pb' uint8*
+FIELDS = [
+    ("B", "i"), ("nb", "i"), ("neq", "i"), ("maxc", "i"), ("fric_dirs", "i"), ("max_cand", "i"), ("max_pc", "i"),
+    ("nmesh", "i"), ("strict_no_pen", "i"), ("toc_diff", "i"), ("lcp_max_iter", "i"),
+    ("eps", "d"), ("tol", "d"), ("dt", "d"),
+    ("pose", "pd"), ("vel", "pd"),
+    ("mass", "pd"), ("inertia", "pd"), ("restitution", "pd"), ("fric", "pd"), ("fext", "pd"),
+    ("shape_type", "pi"), ("shape_prm", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
+    ("mesh_voff", "pi"), ("mesh_nv", "pi"), ("mesh_foff", "pi"), ("mesh_nf", "pi"),
+    ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"),
+    ("Je", "pd"), ("b_eq", "pd"),
+    ("t", "pd"), ("t_end", "pd"), ("dt_try", "pd"), ("last_dt", "pd"), ("dt_use", "pd"),
+    ("active", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
+    ("nc", "pi"), ("c_body", "pi"), ("c_face", "pi"), ("c_abc", "pd"), ("c_geom", "pd"),
+    ("n_nc", "pi"), ("n_body", "pi"), ("n_face", "pi"), ("n_abc", "pd"), ("n_geom", "pd"),
+    ("pose0", "pd"), ("vel0", "pd"),
+    ("Mblk", "pd"), ("pvec", "pd"), ("cop", "pd"), ("x", "pd"), ("lam", "pd"), ("slack", "pd"), ("nu", "pd"),
+    ("cop_body", "pi"), ("lcp_iters", "pi"), ("lcp_status", "pi"),
+    ("ovl", "pi"), ("invalid", "pi"), ("overflow", "pi"),
+    ("pc_count", "pi"), ("pc_face", "pi"), ("pc_abc", "pd"), ("pc_geom", "pd"),
+    ("cand_face", "pi"), ("cand_state", "pi"), ("cand_buf", "pd"),
+    ("max_sub", "i"),
+    ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
+    ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
+    ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"),
+]
+
+
+class DssWorld(ctypes.Structure):
+    _fields_ = [(n, {"i": _I, "d": _D}.get(k, _P)) for n, k in FIELDS]
+
+
+NP_DTYPE = {"pd": np.float64, "pi": np.int32, "pb": np.uint8}
+
+
+def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF):
+    """Shapes of every array the kernels touch (state, scratch, tape)."""
+    npair = nb * (nb - 1)
+    NR = fd + 2
+    NFc = 3 * (1 + fd // 2) + 8
+    nz = 6 * nb
+    s = {
+        "pose": (B, nb, 7), "vel": (B, nb, 6), "mass": (B, nb), "inertia": (B, nb, 9), "restitution": (B, nb),
+        "fric": (B, nb), "fext": (B, nb, 6), "shape_type": (B, nb), "shape_prm": (B, nb, 3), "mesh_id": (B, nb),
+        "no_contact": (nb, nb), "mesh_voff": (nmesh,), "mesh_nv": (nmesh,), "mesh_foff": (nmesh,), "mesh_nf": (nmesh,),
+        "verts": (NV, 3), "faces": (NF, 3), "fcent": (NF, 3), "frad": (NF,),
+        "Je": (B, max(neq, 1), nz), "b_eq": (B, max(neq, 1)),
+        "t": (B,), "t_end": (B,), "dt_try": (B,), "last_dt": (B,), "dt_use": (B,),
+        "active": (B,), "toc": (B,), "nsub": (B,), "n_active": (1,),
+        "nc": (B,), "c_body": (B, 2, maxc), "c_face": (B, maxc), "c_abc": (B, 3, maxc), "c_geom": (B, 10, maxc),
+        "n_nc": (B,), "n_body": (B, 2, maxc), "n_face": (B, maxc), "n_abc": (B, 3, maxc), "n_geom": (B, 10, maxc),
+        "pose0": (B, nb, 7), "vel0": (B, nb, 6),
+        "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
+        "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
+        "ovl": (B, nb, nb), "invalid": (B,), "overflow": (B,),
+        "pc_count": (B, npair), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
+        "pc_geom": (B, npair, 10, max_pc),
+        "cand_face": (B, npair, 2, max_cand), "cand_state": (B, npair, max_cand),
+        "cand_buf": (B, npair, CAND_FIELDS, max_cand),
+    }
+    if max_sub > 0:
+        s.update({
+            "tp_pose": (max_sub, B, nb, 7), "tp_vel": (max_sub, B, nb, 6), "tp_dt": (max_sub, B), "tp_x": (max_sub, B, nz),
+            "tp_lam": (max_sub, B, NR, maxc), "tp_slack": (max_sub, B, NR, maxc), "tp_nu": (max_sub, B, max(neq, 1)),
+            "tp_abc": (max_sub, B, 3, maxc), "tp_geom": (max_sub, B, 10, maxc),
+            "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc),
+        })
+    return s

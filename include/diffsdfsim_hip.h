@@ -84,6 +84,7 @@ size_t dss_lcp_contact_workspace_bytes(int B, int nb, int neq, int maxc, int fri
 
 int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double *A, const double *bvec,
                             const double *cop, const int *cbody, const int *nc,
+                            const int *active /* [B] or NULL: scenes with active[s]==0 are skipped */,
                             int B, int nb, int neq, int maxc, int fric_dirs,
                             double eps, int not_improved_lim, int max_iter,
                             double *x, double *lam, double *slack, double *nu, int *iters, int *status,
@@ -94,6 +95,94 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
                              const double *x, const double *lam, const double *slack, const double *nu,
                              const double *dl_dx,
                              double *dMblk, double *dpvec, double *dcop, double *dA, double *db, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * B3: batched world stepper  --  replaces, for a batch of B independent scenes,
+ *     World.step / step_dt          lcp_physics/physics/world.py:119-139, 241-379
+ *     PdipmEngine.solve_dynamics     lcp_physics/physics/engines.py:31-83   (assembly)
+ *     World3D.M/Jc/Jf, mu, restitutions  sdf_physics/physics3d/world.py:48-101, world.py:402-501
+ *     Body3D.move / set_p            sdf_physics/physics3d/bodies.py:488-511
+ *     FWContactHandler (+_overlap, _frank_wolfe, _compute_contacts, _filter_contacts)
+ *                                    sdf_physics/physics3d/contacts.py:27-272
+ *     SDF3D.query_sdfs + box/sphere  sdf_physics/physics3d/bodies.py:38-95, 721-760
+ * State is struct-of-arrays over the scene axis; all pointers are device pointers owned by
+ * the caller.  One "attempt" = solve -> integrate -> detect -> accept/halve for every active
+ * scene (the reference's retry loop, world.py:249-356, run in lock step across the batch).
+ * ------------------------------------------------------------------------------------ */
+typedef struct DssWorld {
+    /* sizes */
+    int B, nb, neq, maxc, fric_dirs;
+    int max_cand;   /* Frank-Wolfe working set per directed body pair            */
+    int max_pc;     /* contacts kept per directed body pair after filtering      */
+    int nmesh, strict_no_pen, toc_diff /* World3D(time_of_contact_diff=...) */, lcp_max_iter;
+    double eps, tol, dt;   /* Defaults3D.EPSILON / TOL (utils.py:45-48), world dt */
+    /* body state [B][nb][7] / [B][nb][6] */
+    double *pose, *vel;
+    /* body parameters, [B][nb](...) */
+    const double *mass, *inertia /*[9]*/, *restitution, *fric, *fext /*[6]*/;
+    const int *shape_type;      /* DSS_SHAPE_* */
+    const double *shape_prm;    /* [3]: box dims | sphere radius */
+    const int *mesh_id;
+    const unsigned char *no_contact; /* [nb][nb], shared by all scenes */
+    /* mesh table (body frame) */
+    const int *mesh_voff, *mesh_nv, *mesh_foff, *mesh_nf;   /* [nmesh] */
+    const double *verts;   /* [NV][3] */
+    const int *faces;      /* [NF][3] vertex ids local to the mesh */
+    const double *fcent;   /* [NF][3] face centroids, */
+    const double *frad;    /* [NF]    max centroid-vertex distance (both pose invariant) */
+    /* equality rows (joints), constant: Je [B][neq][6 nb], right-hand side b_eq [B][neq] (zeros) */
+    const double *Je, *b_eq;
+    /* per-scene stepping state [B] */
+    double *t, *t_end, *dt_try, *last_dt;
+    double *dt_use;  /* dt_ actually integrated in the current attempt (world.py:251-257) */
+    int *active;     /* 1 while t < t_end in the current outer step */
+    int *toc;        /* reference's `toc_contacts` non-empty */
+    int *nsub;       /* accepted sub-steps so far (tape slot) */
+    int *n_active;   /* [1] number of scenes still active after dss_step_decide */
+    /* current contacts (geometry at the current pose) [B][...] */
+    int *nc;                 /* [B] */
+    int *c_body;             /* [B][2][maxc] */
+    int *c_face;             /* [B][maxc] face id in the mesh of body 1 */
+    double *c_abc;           /* [B][3][maxc] barycentrics */
+    double *c_geom;          /* [B][10][maxc] n(3) p1(3) p2(3) pen */
+    /* contacts detected by the current attempt; committed on accept */
+    int *n_nc, *n_body, *n_face;
+    double *n_abc, *n_geom;
+    /* sub-step start copies (rollback, world.py:344-356) */
+    double *pose0, *vel0;
+    /* LCP operands / results of the current attempt */
+    double *Mblk, *pvec, *cop, *x, *lam, *slack, *nu;
+    int *cop_body, *lcp_iters, *lcp_status;
+    /* narrow phase scratch */
+    int *ovl;                /* [B][nb][nb] overlap flags */
+    int *invalid;            /* [B] penetration > tol found in this attempt */
+    int *overflow;           /* [B] a capacity (max_cand / max_pc / maxc) was exceeded */
+    int *pc_count;           /* [B][npairs] */
+    int *pc_face;            /* [B][npairs][max_pc] */
+    double *pc_abc;          /* [B][npairs][3][max_pc] */
+    double *pc_geom;         /* [B][npairs][10][max_pc] */
+    int *cand_face;          /* [B][npairs][2][max_cand] candidate faces / contact faces */
+    int *cand_state;         /* [B][npairs][max_cand] contact list / cluster ids */
+    double *cand_buf;        /* [B][npairs][DSS_CAND_FIELDS][max_cand] */
+    /* tape for the backward pass: slot-major, [max_sub][B][...] (NULL = do not record) */
+    int max_sub;
+    double *tp_pose, *tp_vel, *tp_dt, *tp_x, *tp_lam, *tp_slack, *tp_nu, *tp_abc, *tp_geom;
+    int *tp_nc, *tp_body, *tp_face;
+} DssWorld;
+
+#define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */
+#define DSS_SHAPE_BOX 0
+#define DSS_SHAPE_SPHERE 1
+
+size_t dss_world_sizeof(void);   /* sizeof(DssWorld): lets a binding check its mirror struct */
+
+/* Start an outer step of length W->dt for every scene: t_end = t + dt, active = 1 (world.py:119-134). */
+int dss_step_begin(const DssWorld *W, void *stream);
+/* One attempt for all active scenes.  Enqueues: assemble -> LCP -> integrate -> detect -> decide.
+ * After it completes W->n_active[0] holds the number of scenes that still have t < t_end.      */
+int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream);
+/* Contact detection only, at the current pose (World.__init__, world.py:96-100). */
+int dss_find_contacts(const DssWorld *W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""Generate G5/G6 golden rollouts (contacts + trajectories + gradients) from the reference's CPU path.
+
+Run in the build container only:  python -m oracle.gen.gen_rollout_golden
+Each tests/golden/rollout_*.npz holds the scene description (incl. the reference's own meshes, so
+both sides search identical triangles), the initial contact set, every accepted sub-step of
+`World3D.step(fixed_dt=True)` (lcp_physics/physics/world.py:119-139,241-379): t, poses, velocities,
+the ordered (body1, body2) list and the contact geometry, and d(sum |pos_T|^2)/d(parameters).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+from oracle.gen import scenes  # noqa: E402
+from sdf_physics.physics3d.world import World3D  # noqa: E402
+from sdf_physics.physics3d.bodies import SDFBox, SDFSphere  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+MAXC = 160
+
+
+def contacts_arrays(contacts):
+    n = len(contacts)
+    body = np.zeros((n, 2), np.int32); geom = np.zeros((n, 10))
+    for k, ((nr, p1, p2, pen), i1, i2) in enumerate(contacts):
+        body[k] = (i1, i2)
+        geom[k, :3] = nr.detach().numpy(); geom[k, 3:6] = p1.detach().numpy(); geom[k, 6:9] = p2.detach().numpy()
+        geom[k, 9] = float(pen)
+    return body, geom
+
+
+def describe(bodies, g=10.0):
+    d = {}
+    nb = len(bodies)
+    d["shape_type"] = np.array([0 if isinstance(b, SDFBox) else 1 for b in bodies], np.int32)
+    prm = np.zeros((nb, 3))
+    for i, b in enumerate(bodies):
+        if isinstance(b, SDFBox):
+            prm[i] = b.dims.detach().numpy()
+        else:
+            prm[i, 0] = float(b.rad)
+    d["shape_prm"] = prm
+    d["pose0"] = np.stack([b.p.detach().numpy() for b in bodies])
+    d["vel0"] = np.stack([b.v.detach().numpy() for b in bodies])
+    d["mass"] = np.array([float(b.mass) for b in bodies])
+    d["inertia"] = np.stack([b.ang_inertia.detach().numpy() for b in bodies])
+    d["restitution"] = np.array([float(b.restitution) for b in bodies])
+    d["fric"] = np.array([float(b.fric_coeff) for b in bodies])
+    d["fext"] = np.stack([b.apply_forces(0.0).detach().numpy() for b in bodies])
+    for i, b in enumerate(bodies):
+        d["verts_%d" % i] = b.verts.detach().numpy()
+        d["faces_%d" % i] = b.faces.numpy().astype(np.int32)
+    return d
+
+
+def run(name, bodies, joints, params, nsteps, toc=True, fixed=(0,)):
+    d = describe(bodies)
+    w = World3D(bodies, joints, time_of_contact_diff=toc)
+    d["dt"], d["eps"], d["tol"], d["fric_dirs"], d["toc_diff"] = w.dt, w.eps, w.tol, w.fric_dirs, int(toc)
+    d["fixed"] = np.array(fixed, np.int32)
+    b0, g0 = contacts_arrays(w.contacts)
+    d["init_body"], d["init_geom"] = b0, g0
+    for _ in range(nsteps):
+        w.step(fixed_dt=True)
+    T = len(w.trajectory)
+    nb = len(bodies)
+    d["traj_t"] = np.array([float(e[0]) for e in w.trajectory])
+    d["traj_p"] = np.stack([e[1].detach().numpy().reshape(nb, 7) for e in w.trajectory])
+    d["traj_v"] = np.stack([e[2].detach().numpy().reshape(nb, 6) for e in w.trajectory])
+    nc = np.array([len(e[3]) for e in w.trajectory], np.int32)
+    cb = np.zeros((T, MAXC, 2), np.int32); cg = np.zeros((T, MAXC, 10))
+    for k, e in enumerate(w.trajectory):
+        b, g = contacts_arrays(e[3])
+        cb[k, :len(b)] = b; cg[k, :len(b)] = g
+    d["traj_nc"], d["traj_body"], d["traj_geom"] = nc, cb, cg
+    d["t_final"] = float(w.t)
+    loss = sum((b.pos ** 2).sum() for b in bodies)
+    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    for i, (p, g) in enumerate(zip(params, grads)):
+        d["param_%d" % i] = p.detach().numpy()
+        d["grad_%d" % i] = np.zeros_like(p.detach().numpy()) if g is None else g.numpy()
+    d["loss"] = float(loss)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "substeps", T, "for", nsteps, "steps; nc range", nc.min(), nc.max(), "loss", float(loss),
+          "grads", [np.abs(d["grad_%d" % i]).max() for i in range(len(params))])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    bodies, joints, params = scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0))
+    run("rollout_sphere", bodies, joints, params, nsteps=24)
+    bodies, joints, params = scenes.box_stack(nbox=1, seed=3, vel_scale=1.0, push=2.0)
+    run("rollout_stack1", bodies, joints, params, nsteps=4)
+    bodies, joints, params = scenes.box_stack(nbox=2, seed=4, vel_scale=0.5, push=1.5)
+    run("rollout_stack2", bodies, joints, params, nsteps=3)
+
+
+if __name__ == "__main__":
+    main()

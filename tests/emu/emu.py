@@ -70,7 +70,7 @@ def lcp_contact_forward(P, eps=1e-12, nil=3, max_iter=10):
     iters = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
     nbytes = L.dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fd)
     ws = np.zeros(nbytes, np.uint8)
-    rc = L.dss_lcp_contact_forward(_p(Mblk), _p(pvec), _p(A), _p(bvec), _p(cop), _p(cbody), _p(nc), B, nb, neq, maxc, fd,
+    rc = L.dss_lcp_contact_forward(_p(Mblk), _p(pvec), _p(A), _p(bvec), _p(cop), _p(cbody), _p(nc), None, B, nb, neq, maxc, fd,
                                    ctypes.c_double(eps), nil, max_iter, _p(x), _p(lam), _p(slack), _p(nu), _p(iters),
                                    _p(status), _p(ws), ctypes.c_size_t(nbytes), None)
     assert rc == 0, rc
@@ -90,3 +90,28 @@ def lcp_contact_backward(P, x, lam, slack, nu, dl):
                                     _p(slack), _p(nu), _p(dl), _p(dM), _p(dp), _p(dcop), _p(dA), _p(db), None)
     assert rc == 0, rc
     return dM, dp, dcop, dA, db
+
+
+class EmuBackend:
+    """numpy arrays + the CPU emulation build; plugs into diffsdfsim_amd.engine.BatchEngine for logic tests."""
+
+    def __init__(self):
+        self.lib = lib()
+
+    def zeros(self, shape, dtype):
+        return np.zeros(shape, dtype)
+
+    def from_numpy(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def to_numpy(self, t):
+        return t
+
+    def ptr(self, t):
+        return t.ctypes.data
+
+    def stream(self):
+        return None
+
+    def read_int(self, t):
+        return int(t.reshape(-1)[0])

@@ -30,6 +30,7 @@ struct emu_uint3 { unsigned x, y, z; };
 #define __launch_bounds__(...)
 #define __align__(n)
 #define __restrict__
+#define __shared__ static
 
 typedef void *hipStream_t;
 typedef int hipError_t;
@@ -137,6 +138,35 @@ template <class T> inline T __shfl_down(T v, int d, int = 64)
     int l = dss_emu::st().cur & 63;
     return dss_emu::shfl_from(v, l + d < 64 ? l + d : l);
 }
+// block-wide predicate reductions: every fiber deposits its predicate, all read after the switch
+inline int emu_block_reduce(int pred, int mode)
+{
+    dss_emu::State &s = dss_emu::st();
+    s.slots[s.cur] = (uint64_t)(pred != 0);
+    dss_emu::yield();
+    int acc = (mode == 1) ? 1 : 0;
+    for (size_t i = 0; i < s.slots.size(); ++i) {
+        int v = (int)s.slots[i];
+        if (mode == 0) acc |= v; else if (mode == 1) acc &= v; else acc += v;
+    }
+    dss_emu::yield();
+    return acc;
+}
+inline int __syncthreads_or(int p) { return emu_block_reduce(p, 0); }
+inline int __syncthreads_and(int p) { return emu_block_reduce(p, 1); }
+inline int __syncthreads_count(int p) { return emu_block_reduce(p, 2); }
+inline unsigned long long __ballot(int pred)
+{
+    dss_emu::State &s = dss_emu::st();
+    s.slots[s.cur] = (uint64_t)(pred != 0);
+    dss_emu::yield();
+    unsigned long long m = 0;
+    int base = (s.cur / 64) * 64;
+    for (int i = 0; i < 64 && base + i < (int)s.slots.size(); ++i) m |= (unsigned long long)(s.slots[base + i] & 1) << i;
+    dss_emu::yield();
+    return m;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
