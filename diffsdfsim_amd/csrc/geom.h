@@ -18,6 +18,14 @@
 
 #include "dss_device.h"
 
+// The reference breaks exact ties (arg-min vertex of a flat triangle, Laplacian comparison of two flat
+// faces) on the last bit of un-fused IEEE arithmetic.  Translation units that include this header keep
+// mul/add un-contracted so the device takes the same branches as the CPU reference wherever the inputs
+// agree bit for bit (the LCP kernels do not include it and keep FMA contraction).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace dss {
 
 template <int N> struct Dual {
@@ -99,6 +107,14 @@ template <class T> __host__ __device__ inline T t_clamp_max(const T &x, double h
 // select by value; ties go to the first argument (index-0-wins like torch.max(dim).indices on CPU)
 template <class T> __host__ __device__ inline T t_max(const T &a, const T &b) { return val(b) > val(a) ? b : a; }
 template <class T> __host__ __device__ inline T t_min(const T &a, const T &b) { return val(b) < val(a) ? b : a; }
+// elementwise torch.max(a, b) / torch.maximum: at an exact tie autograd gives each argument half the gradient
+__host__ __device__ inline double t_maximum(double a, double b) { return a > b ? a : b; }
+template <int N> __host__ __device__ inline Dual<N> t_maximum(const Dual<N> &a, const Dual<N> &b)
+{
+    if (a.v > b.v) return a;
+    if (b.v > a.v) return b;
+    return (a + b) * 0.5;
+}
 
 template <class T> struct V3 { T x[3]; };
 
@@ -242,7 +258,7 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
         if (want_grad) {
             // box_sdf_grad: failsafe diagonal normals on ties (bodies.py:51-72); m = max(q, 0)
             T mg[3], nm[3], go[3];
-            for (int i = 0; i < 3; ++i) mg[i] = t_max(q[i], T(0.0));
+            for (int i = 0; i < 3; ++i) mg[i] = t_maximum(q[i], T(0.0));   // torch.max(q, zeros): ties split
             normalize(mg, nm);
             for (int i = 0; i < 3; ++i) {
                 const double sg = val(p[i]) < 0.0 ? -1.0 : 1.0;

@@ -672,13 +672,14 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 template <int ND>
 __global__ void __launch_bounds__(64)
 lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double *cop_, const int *cbody_,
-                            const int *ncs, int nb, int neq, int maxc, const double *x_, const double *lam_,
+                            const int *ncs, const int *active, int nb, int neq, int maxc, const double *x_, const double *lam_,
                             const double *slack_, const double *nu_, const double *dl_dx_, double *dMblk_,
                             double *dpvec_, double *dcop_, double *dA_, double *db_)
 {
     constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
     DSS_DYN_LDS(double, ldsmem);
     const int sc = blockIdx.x, lane = lane_id();
+    if (active && !active[sc]) return;
     Lds L;
     carve_lds(L, ldsmem, nb, neq, maxc);
     const int nz = L.nz, n = L.n;
@@ -815,7 +816,7 @@ int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double
 }
 
 int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
-                             int B, int nb, int neq, int maxc, int fric_dirs, const double *x, const double *lam,
+                             const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x, const double *lam,
                              const double *slack, const double *nu, const double *dl_dx, double *dMblk,
                              double *dpvec, double *dcop, double *dA, double *db, void *stream)
 {
@@ -827,10 +828,10 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_backward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
     else
         hipLaunchKernelGGL(lcp_contact_backward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 

@@ -1,0 +1,342 @@
+// step_bwd.hip -- reverse sweep over the stepper's tape (gfx950).
+//
+// One call of dss_step_backward undoes one accepted sub-step per scene (the newest unprocessed one):
+//
+//   bwd_pre_kernel    (a) adjoint of the contact geometry that was computed at the END of the
+//                         sub-step (contacts.py:161-214 on the filtered set) -> pose, shape params
+//                     (b) adjoint of Body3D.move (bodies.py:488-511)       -> start pose, new velocity
+//                     (c) re-assembles the sub-step's LCP operands from the tape (engines.py:36-81)
+//   lcp_contact_backward   implicit differentiation of the LCP (lcp.py:156-213)
+//   bwd_post_kernel   adjoint of the assembly: u = M v + dt f, M = blockdiag(R I R^T, m),
+//                     friction directions, mu / restitution averages, h = (Jc v) e
+//                     (engines.py:36-81, physics3d/world.py:48-101, world.py:400-501)
+//
+// Small nonlinear stages are differentiated with forward-mode duals (geom.h) seeded a few inputs at a
+// time and contracted with the incoming adjoint; linear stages are transposed by hand.  Sums over the
+// contacts of a body run in contact order (no atomics): gradients are bit-reproducible.
+#include <math.h>
+
+#include "../../include/diffsdfsim_hip.h"
+#include "contact_geom.h"
+#include "wave_utils.h"
+
+namespace {
+using namespace dss;
+
+struct SlotView {   // where the data of "sub-step k" and of "the state after it" live
+    const double *pose_k, *vel_k;               // [nb][7], [nb][6] start of sub-step k
+    const double *pose_n;                       // [nb][7] pose after sub-step k
+    double dt;
+    int nc_k; const int *body_k; const double *geom_k;                   // contacts used by the LCP of k
+    int nc_n; const int *body_n, *face_n; const double *abc_n;           // contacts detected after k
+    const double *x, *lam, *slack, *nu;
+};
+
+__device__ inline void view_slot(const DssWorld &W, int sc, int k, SlotView &v)
+{
+    const int nb = W.nb, MX = W.maxc, NR = W.fric_dirs + 2;
+    const size_t rec = (size_t)k * W.B + sc;
+    v.pose_k = W.tp_pose + rec * nb * 7;
+    v.vel_k = W.tp_vel + rec * nb * 6;
+    v.dt = W.tp_dt[rec];
+    v.nc_k = W.tp_nc[rec];
+    v.body_k = W.tp_body + rec * 2 * MX;
+    v.geom_k = W.tp_geom + rec * 10 * MX;
+    v.x = W.tp_x + rec * 6 * nb;
+    v.lam = W.tp_lam + rec * NR * MX;
+    v.slack = W.tp_slack + rec * NR * MX;
+    v.nu = W.tp_nu + rec * (W.neq > 0 ? W.neq : 1);
+    if (k + 1 < W.nsub[sc]) {
+        const size_t r2 = (size_t)(k + 1) * W.B + sc;
+        v.pose_n = W.tp_pose + r2 * nb * 7;
+        v.nc_n = W.tp_nc[r2]; v.body_n = W.tp_body + r2 * 2 * MX; v.face_n = W.tp_face + r2 * MX; v.abc_n = W.tp_abc + r2 * 3 * MX;
+    } else {
+        v.pose_n = W.pose + (size_t)sc * nb * 7;
+        v.nc_n = W.nc[sc]; v.body_n = W.c_body + (size_t)sc * 2 * MX; v.face_n = W.c_face + (size_t)sc * MX;
+        v.abc_n = W.c_abc + (size_t)sc * 3 * MX;
+    }
+}
+
+// d(n, p1, p2)/d(pose1, pose2, prm1, prm2) contracted with gbar[9]; out[20]
+__device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
+                            const double *abc, const double *gbar, double *out)
+{
+    constexpr int N = 4;
+    typedef Dual<N> D;
+    const int nb = W.nb;
+    const double *P1 = pose_n + 7 * b1, *P2 = pose_n + 7 * b2;
+    const double *prm1 = W.shape_prm + ((size_t)sc * nb + b1) * 3, *prm2 = W.shape_prm + ((size_t)sc * nb + b2) * 3;
+    const int ty1 = W.shape_type[(size_t)sc * nb + b1], ty2 = W.shape_type[(size_t)sc * nb + b2];
+    const int mesh = W.mesh_id[(size_t)sc * nb + b1];
+    const int voff = W.mesh_voff[mesh], foff = W.mesh_foff[mesh];
+    const int *fv = W.faces + (size_t)(foff + face) * 3;
+    for (int grp = 0; grp < 5; ++grp) {
+        BodyG<D> B1, B2;
+        D pr1[3], pr2[3];
+        auto seed = [&](int t, double v) { D d(v); const int s = t - N * grp; if (s >= 0 && s < N) d.d[s] = 1.0; return d; };
+        for (int i = 0; i < 4; ++i) { B1.q[i] = seed(i, P1[i]); B2.q[i] = seed(7 + i, P2[i]); }
+        for (int i = 0; i < 3; ++i) {
+            B1.pos[i] = seed(4 + i, P1[4 + i]); B2.pos[i] = seed(11 + i, P2[4 + i]);
+            pr1[i] = seed(14 + i, prm1[i]); pr2[i] = seed(17 + i, prm2[i]);
+        }
+        make_shape(B1.shape, ty1, pr1);
+        make_shape(B2.shape, ty2, pr2);
+        D tri[3][3];
+        for (int v = 0; v < 3; ++v)
+            for (int i = 0; i < 3; ++i) {
+                const double val0 = W.verts[(size_t)(voff + fv[v]) * 3 + i], gr = W.vgrad[(size_t)(voff + fv[v]) * 3 + i];
+                D d(val0);
+                const int t = (ty1 == SHAPE_BOX) ? 14 + i : 14, s = t - N * grp;  // box: own axis; sphere: radius
+                if (s >= 0 && s < N) d.d[s] = gr;
+                tri[v][i] = d;
+            }
+        D n[3], p1[3], p2[3], pen;
+        contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen);
+        for (int s = 0; s < N; ++s) {
+            double acc = 0.0;
+            for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + gbar[3 + i] * p1[i].d[s] + gbar[6 + i] * p2[i].d[s];
+            out[N * grp + s] = acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
+{
+    const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
+    const int k = A.cur_slot[sc];
+    const int act = (k >= 0 && k >= A.lo_slot[sc] && k < W.nsub[sc]);
+    // slot -1 = the contacts found at construction (World.__init__, world.py:96): only their geometry
+    // adjoint is left to push onto the initial pose and the shape parameters
+    const int init = (k == -1 && A.lo_slot[sc] <= -1 && W.nsub[sc] > 0);
+    if (lane == 0) A.bw_active[sc] = act;
+    if (!act && !init) return;
+    SlotView v;
+    double *a_pose = A.a_pose + (size_t)sc * nb * 7, *a_vel = A.a_vel + (size_t)sc * nb * 6;
+    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * 20 * MX;
+    if (init) {
+        const size_t r0 = (size_t)sc;   // tape slot 0
+        v.pose_n = W.tp_pose + r0 * nb * 7;
+        v.nc_n = W.tp_nc[r0]; v.body_n = W.tp_body + r0 * 2 * MX; v.face_n = W.tp_face + r0 * MX; v.abc_n = W.tp_abc + r0 * 3 * MX;
+    } else {
+        view_slot(W, sc, k, v);
+    }
+
+    // (a) contacts detected after the sub-step: geometry adjoint -> pose after the sub-step, shape params
+    for (int c = lane; c < v.nc_n; c += 64) {
+        double gb[9], out[20];
+        for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
+        const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
+        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out);
+        for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
+    }
+    __syncthreads();
+    if (lane < nb) {
+        double ap[7], gp[3] = {0, 0, 0};
+        for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i];
+        for (int c = 0; c < v.nc_n; ++c) {
+            if (v.body_n[c] == lane) {
+                for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)i * MX + c];
+                for (int i = 0; i < 3; ++i) gp[i] += cs[(size_t)(14 + i) * MX + c];
+            }
+            if (v.body_n[MX + c] == lane) {
+                for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)(7 + i) * MX + c];
+                for (int i = 0; i < 3; ++i) gp[i] += cs[(size_t)(17 + i) * MX + c];
+            }
+        }
+        for (int i = 0; i < 3; ++i) A.g_prm[((size_t)sc * nb + lane) * 3 + i] += gp[i];
+        for (int i = 0; i < 7; ++i) a_pose[7 * lane + i] = ap[i];
+    }
+    if (init) {
+        __syncthreads();
+        for (int c = lane; c < MX; c += 64) for (int i = 0; i < 10; ++i) a_geom[(size_t)i * MX + c] = 0.0;
+        if (lane == 0) A.cur_slot[sc] = -2;
+        return;
+    }
+    if (lane < nb) {
+        double ap[7];
+        for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i] ;
+        // (b) pose_n = integrate(pose_k, v_new, dt): adjoint -> pose_k, v_new
+        double vnew[6], apk[7], avn[6];
+        for (int i = 0; i < 6; ++i) vnew[i] = -v.x[6 * lane + i];
+        {
+            typedef Dual<7> D;
+            D ps[7], vv[6], out[7], dt(v.dt);
+            for (int i = 0; i < 7; ++i) { ps[i] = D(v.pose_k[7 * lane + i]); ps[i].d[i] = 1.0; }
+            for (int i = 0; i < 6; ++i) vv[i] = D(vnew[i]);
+            integrate_pose(ps, vv, dt, out);
+            for (int s = 0; s < 7; ++s) { double acc = 0.0; for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[s]; apk[s] = acc; }
+        }
+        {
+            typedef Dual<6> D;
+            D ps[7], vv[6], out[7], dt(v.dt);
+            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
+            for (int i = 0; i < 6; ++i) { vv[i] = D(vnew[i]); vv[i].d[i] = 1.0; }
+            integrate_pose(ps, vv, dt, out);
+            for (int s = 0; s < 6; ++s) { double acc = 0.0; for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[s]; avn[s] = acc; }
+        }
+        for (int i = 0; i < 7; ++i) a_pose[7 * lane + i] = apk[i];
+        // total adjoint of v_new = (later uses, already in a_vel) + (integration); x = -v_new
+        for (int i = 0; i < 6; ++i) A.a_x[(size_t)sc * 6 * nb + 6 * lane + i] = -(a_vel[6 * lane + i] + avn[i]);
+        // (c) LCP operands of sub-step k: mass blocks
+        const size_t bi = (size_t)sc * nb + lane;
+        double Iw[9];
+        world_inertia(v.pose_k + 7 * lane, W.inertia + bi * 9, Iw);
+        double *M = W.Mblk + bi * 36;
+        const double m = W.mass[bi];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) M[6 * r + c] = (r < 3 && c < 3) ? Iw[3 * r + c] : ((r == c) ? m : 0.0);
+        for (int i = 0; i < 6; ++i) W.x[(size_t)sc * 6 * nb + 6 * lane + i] = v.x[6 * lane + i];
+    }
+    if (lane < W.neq) W.nu[(size_t)sc * W.neq + lane] = v.nu[lane];
+    const int ND = W.fric_dirs / 2, NF = 3 * (1 + ND) + 8, NR = W.fric_dirs + 2;
+    double *cop = W.cop + (size_t)sc * NF * MX;
+    for (int c = lane; c < v.nc_k; c += 64) {
+        const int b1 = v.body_k[c], b2 = v.body_k[MX + c];
+        W.cop_body[(size_t)sc * 2 * MX + c] = b1;
+        W.cop_body[(size_t)sc * 2 * MX + MX + c] = b2;
+        double n[3], p1[3], p2[3], D[4][3];
+        for (int i = 0; i < 3; ++i) { n[i] = v.geom_k[(size_t)i * MX + c]; p1[i] = v.geom_k[(size_t)(3 + i) * MX + c]; p2[i] = v.geom_k[(size_t)(6 + i) * MX + c]; }
+        friction_dirs(n, ND, D);
+        for (int i = 0; i < 3; ++i) {
+            cop[(size_t)i * MX + c] = n[i];
+            for (int q = 0; q < ND; ++q) cop[(size_t)(3 * (q + 1) + i) * MX + c] = D[q][i];
+        }
+        const int o = 3 * (1 + ND);
+        for (int i = 0; i < 3; ++i) { cop[(size_t)(o + i) * MX + c] = p1[i]; cop[(size_t)(o + 3 + i) * MX + c] = p2[i]; }
+        cop[(size_t)(o + 6) * MX + c] = 0.5 * (W.fric[(size_t)sc * nb + b1] + W.fric[(size_t)sc * nb + b2]);
+        cop[(size_t)(o + 7) * MX + c] = 0.0;  // h does not enter the backward system (lcp.py:176-183)
+        for (int q = 0; q < NR; ++q) {
+            W.lam[((size_t)sc * NR + q) * MX + c] = v.lam[(size_t)q * MX + c];
+            W.slack[((size_t)sc * NR + q) * MX + c] = v.slack[(size_t)q * MX + c];
+        }
+    }
+    if (lane == 0) A.bw_nc[sc] = v.nc_k;
+}
+
+__global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
+{
+    const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
+    if (!A.bw_active[sc]) return;
+    const int k = A.cur_slot[sc];
+    SlotView v;
+    view_slot(W, sc, k, v);
+    const int ND = W.fric_dirs / 2, NF = 3 * (1 + ND) + 8, o = 3 * (1 + ND);
+    double *a_pose = A.a_pose + (size_t)sc * nb * 7, *a_vel = A.a_vel + (size_t)sc * nb * 6;
+    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * 20 * MX;
+    const double *dcop = A.dcop + (size_t)sc * NF * MX, *dM = A.dMblk + (size_t)sc * nb * 36, *du = A.dpvec + (size_t)sc * 6 * nb;
+
+    // contacts of sub-step k: adjoint of (dirs, p1, p2, mu, h_n) -> geometry, friction, restitution, velocities
+    for (int c = lane; c < MX; c += 64) {
+        if (c >= v.nc_k) { for (int i = 0; i < 10; ++i) a_geom[(size_t)i * MX + c] = 0.0; continue; }
+        const int b1 = v.body_k[c], b2 = v.body_k[MX + c];
+        const size_t i1 = (size_t)sc * nb + b1, i2 = (size_t)sc * nb + b2;
+        double n[3], p1[3], p2[3], nbar[3], p1bar[3], p2bar[3];
+        for (int i = 0; i < 3; ++i) {
+            n[i] = v.geom_k[(size_t)i * MX + c]; p1[i] = v.geom_k[(size_t)(3 + i) * MX + c]; p2[i] = v.geom_k[(size_t)(6 + i) * MX + c];
+            nbar[i] = dcop[(size_t)i * MX + c]; p1bar[i] = dcop[(size_t)(o + i) * MX + c]; p2bar[i] = dcop[(size_t)(o + 3 + i) * MX + c];
+        }
+        {   // friction directions D_q(n)
+            typedef Dual<3> D;
+            D nd[3], Dq[4][3];
+            for (int i = 0; i < 3; ++i) { nd[i] = D(n[i]); nd[i].d[i] = 1.0; }
+            friction_dirs(nd, ND, Dq);
+            for (int s = 0; s < 3; ++s) {
+                double acc = 0.0;
+                for (int q = 0; q < ND; ++q) for (int i = 0; i < 3; ++i) acc += dcop[(size_t)(3 * (q + 1) + i) * MX + c] * Dq[q][i].d[s];
+                nbar[s] += acc;
+            }
+        }
+        const double mubar = dcop[(size_t)(o + 6) * MX + c], hbar = dcop[(size_t)(o + 7) * MX + c];
+        const double *v1 = v.vel_k + 6 * b1, *v2 = v.vel_k + 6 * b2;
+        double c1[3], c2[3], jv = 0.0;
+        cross(p1, n, c1);
+        cross(p2, n, c2);
+        for (int i = 0; i < 3; ++i) jv += c1[i] * v1[i] + n[i] * v1[3 + i] - c2[i] * v2[i] - n[i] * v2[3 + i];
+        const double rc = 0.5 * (W.restitution[i1] + W.restitution[i2]);
+        const double jvbar = hbar * rc, rcbar = hbar * jv;
+        // jv = n . ((w1 x p1) + u1 - (w2 x p2) - u2)
+        double w1p[3], w2p[3], nw1[3], nw2[3];
+        cross(v1, p1, w1p);
+        cross(v2, p2, w2p);
+        cross(n, v1, nw1);
+        cross(n, v2, nw2);
+        for (int i = 0; i < 3; ++i) {
+            nbar[i] += jvbar * (w1p[i] + v1[3 + i] - w2p[i] - v2[3 + i]);
+            p1bar[i] += jvbar * nw1[i];
+            p2bar[i] -= jvbar * nw2[i];
+            a_geom[(size_t)i * MX + c] = nbar[i];
+        }
+        for (int i = 0; i < 3; ++i) { a_geom[(size_t)(3 + i) * MX + c] = p1bar[i]; a_geom[(size_t)(6 + i) * MX + c] = p2bar[i]; }
+        a_geom[(size_t)9 * MX + c] = 0.0;
+        // per-contact pieces for the ordered per-body sums: velocity adjoints (12), mu, restitution
+        for (int i = 0; i < 3; ++i) {
+            cs[(size_t)i * MX + c] = jvbar * c1[i]; cs[(size_t)(3 + i) * MX + c] = jvbar * n[i];
+            cs[(size_t)(6 + i) * MX + c] = -jvbar * c2[i]; cs[(size_t)(9 + i) * MX + c] = -jvbar * n[i];
+        }
+        cs[(size_t)12 * MX + c] = 0.5 * mubar;
+        cs[(size_t)13 * MX + c] = 0.5 * rcbar;
+    }
+    __syncthreads();
+    if (lane < nb) {
+        const size_t bi = (size_t)sc * nb + lane;
+        const double *vk = v.vel_k + 6 * lane, *ub = du + 6 * lane;
+        double Iw[9], av[6], Iwbar[9];
+        world_inertia(v.pose_k + 7 * lane, W.inertia + bi * 9, Iw);
+        const double m = W.mass[bi];
+        // u = M v + dt f
+        for (int r = 0; r < 3; ++r) {
+            av[r] = Iw[r] * ub[0] + Iw[3 + r] * ub[1] + Iw[6 + r] * ub[2];   // Iw^T ubar
+            av[3 + r] = m * ub[3 + r];
+        }
+        double mbar = ub[3] * vk[3] + ub[4] * vk[4] + ub[5] * vk[5] + dM[36 * lane + 21] + dM[36 * lane + 28] + dM[36 * lane + 35];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Iwbar[3 * r + c] = ub[r] * vk[c] + dM[36 * lane + 6 * r + c];
+        for (int i = 0; i < 6; ++i) A.g_fext[bi * 6 + i] += v.dt * ub[i];
+        double fricb = 0.0, restb = 0.0;
+        for (int c = 0; c < v.nc_k; ++c) {
+            if (v.body_k[c] == lane) { for (int i = 0; i < 6; ++i) av[i] += cs[(size_t)i * MX + c]; fricb += cs[(size_t)12 * MX + c]; restb += cs[(size_t)13 * MX + c]; }
+            if (v.body_k[MX + c] == lane) { for (int i = 0; i < 6; ++i) av[i] += cs[(size_t)(6 + i) * MX + c]; fricb += cs[(size_t)12 * MX + c]; restb += cs[(size_t)13 * MX + c]; }
+        }
+        for (int i = 0; i < 6; ++i) a_vel[6 * lane + i] = av[i];
+        A.g_mass[bi] += mbar;
+        A.g_fric[bi] += fricb;
+        A.g_rest[bi] += restb;
+        // Iw = R Ib R^T : Ib_bar = R^T Iw_bar R (linear), q_bar by duals
+        double R[9], t[9];
+        quat_to_mat(v.pose_k + 7 * lane, R);
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) t[3 * a + b] = R[a] * Iwbar[b] + R[3 + a] * Iwbar[3 + b] + R[6 + a] * Iwbar[6 + b];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) A.g_inertia[bi * 9 + 3 * a + b] += t[3 * a] * R[b] + t[3 * a + 1] * R[3 + b] + t[3 * a + 2] * R[6 + b];
+        {
+            typedef Dual<4> D;
+            D q[4], Ib[9], out[9];
+            for (int i = 0; i < 4; ++i) { q[i] = D(v.pose_k[7 * lane + i]); q[i].d[i] = 1.0; }
+            for (int i = 0; i < 9; ++i) Ib[i] = D(W.inertia[bi * 9 + i]);
+            world_inertia(q, Ib, out);
+            for (int s = 0; s < 4; ++s) { double acc = 0.0; for (int e = 0; e < 9; ++e) acc += Iwbar[e] * out[e].d[s]; a_pose[7 * lane + s] += acc; }
+        }
+    }
+    if (lane == 0) A.cur_slot[sc] = k - 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dss_adjoint_sizeof(void) { return sizeof(DssAdjoint); }
+
+int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream_)
+{
+    if (!W || !A || !W->tp_pose) return DSS_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(bwd_pre_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
+    int rc = dss_lcp_contact_backward(W->Mblk, W->Je, W->cop, W->cop_body, A->bw_nc, A->bw_active, W->B, W->nb, W->neq,
+                                      W->maxc, W->fric_dirs, W->x, W->lam, W->slack, W->nu, A->a_x, A->dMblk, A->dpvec,
+                                      A->dcop, nullptr, nullptr, stream_);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd_post_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+}  // extern "C"

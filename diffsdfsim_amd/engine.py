@@ -51,7 +51,19 @@ class TorchBackend:
         return int(t.item())
 
 
-def mesh_table(meshes):
+def default_vgrad(shape_type, prm, verts):
+    """d vertex / d shape parameter of the analytic meshes (bodies.py:803-813 box, :1004-1007 sphere).
+
+    Box: only coordinates that ARE +-dims/2 carry a gradient (the reference re-ties the linspace ends),
+    d v_k / d dims_k = sign/2.  Sphere: verts = unit * rad, d v / d rad = v / rad."""
+    verts = np.asarray(verts, np.float64)
+    if shape_type == abi.SHAPE_BOX:
+        hd = np.asarray(prm, np.float64)[:3] / 2
+        return np.where(np.abs(verts) == hd[None, :], 0.5 * np.sign(verts), 0.0)
+    return verts / float(prm[0])
+
+
+def mesh_table(meshes, vgrads=None):
     """Concatenate (verts, faces) meshes; precompute pose-invariant face centroids and radii."""
     voff, nv, foff, nf, V, F, C, R = [], [], [], [], [], [], [], []
     vo = fo = 0
@@ -64,8 +76,10 @@ def mesh_table(meshes):
         V.append(verts); F.append(faces.astype(np.int32)); C.append(cen); R.append(rad)
         vo += len(verts); fo += len(faces)
     i32 = lambda x: np.asarray(x, np.int32)
-    return dict(mesh_voff=i32(voff), mesh_nv=i32(nv), mesh_foff=i32(foff), mesh_nf=i32(nf),
-                verts=np.concatenate(V), faces=np.concatenate(F), fcent=np.concatenate(C), frad=np.concatenate(R))
+    out = dict(mesh_voff=i32(voff), mesh_nv=i32(nv), mesh_foff=i32(foff), mesh_nf=i32(nf),
+               verts=np.concatenate(V), faces=np.concatenate(F), fcent=np.concatenate(C), frad=np.concatenate(R))
+    out["vgrad"] = np.concatenate([np.asarray(g, np.float64) for g in vgrads]) if vgrads is not None else np.zeros_like(out["verts"])
+    return out
 
 
 class BatchEngine:
@@ -81,7 +95,16 @@ class BatchEngine:
         neq = Je.shape[1]
         self.B, self.nb, self.neq, self.maxc, self.fd = B, nb, neq, maxc, fric_dirs
         self.max_sub = max_sub
-        mt = mesh_table(spec["meshes"])
+        vg = spec.get("mesh_vgrad")
+        if vg is None:   # derive from the first body that uses each mesh
+            mid = np.asarray(spec["mesh_id"]).reshape(B * nb)
+            st = np.asarray(spec["shape_type"]).reshape(B * nb)
+            sp = np.asarray(spec["shape_prm"], np.float64).reshape(B * nb, 3)
+            vg = []
+            for m, (verts, _f) in enumerate(spec["meshes"]):
+                j = int(np.nonzero(mid == m)[0][0])
+                vg.append(default_vgrad(int(st[j]), sp[j], verts))
+        mt = mesh_table(spec["meshes"], vg)
         shapes = abi.array_shapes(B, nb, neq, maxc, fric_dirs, max_cand, max_pc, max_sub, len(spec["meshes"]),
                                   len(mt["verts"]), len(mt["faces"]))
         kinds = dict(abi.FIELDS)
@@ -157,3 +180,26 @@ class BatchEngine:
                 raise RuntimeError("step did not finish within %d attempts" % max_attempts)
         self.attempts += k
         return k
+
+    # -- backward ----------------------------------------------------------------------------------
+    def _adjoint(self):
+        if getattr(self, "adj", None) is None:
+            shp = abi.adjoint_shapes(self.B, self.nb, self.maxc, self.fd)
+            kinds = dict(abi.ADJ_FIELDS)
+            self.adj = {n: self.be.zeros(s, abi.NP_DTYPE[kinds[n]]) for n, s in shp.items()}
+            A = abi.DssAdjoint()
+            for n, _k in abi.ADJ_FIELDS:
+                setattr(A, n, self.be.ptr(self.adj[n]))
+            self.A = A
+            L = self.be.lib
+            L.dss_adjoint_sizeof.restype = ctypes.c_size_t
+            if L.dss_adjoint_sizeof() != ctypes.sizeof(abi.DssAdjoint):
+                raise RuntimeError("DssAdjoint layout mismatch")
+        return self.adj
+
+    def backward_sweep(self, n_iter):
+        """Run ``n_iter`` reverse sub-step sweeps (each undoes at most one sub-step per scene)."""
+        self._adjoint()
+        L = self.be.lib
+        for _ in range(n_iter):
+            self._check(L.dss_step_backward(ctypes.byref(self.W), ctypes.byref(self.A), self.be.stream()), "dss_step_backward")

@@ -58,7 +58,7 @@ def lcp_contact_backward(Mblk, A, cop, cbody, nc, fric_dirs, x, lam, slack, nu, 
     dcop = torch.empty_like(cop)
     dA = torch.empty(B, neq, 6 * nb, **f64) if want_dA and neq else None
     db = torch.empty(B, neq, **f64) if want_dA and neq else None
-    rc = L.dss_lcp_contact_backward(_lib.ptr(Mblk), _lib.ptr(A), _lib.ptr(cop), _lib.ptr(cbody), _lib.ptr(nc), B, nb, neq,
+    rc = L.dss_lcp_contact_backward(_lib.ptr(Mblk), _lib.ptr(A), _lib.ptr(cop), _lib.ptr(cbody), _lib.ptr(nc), None, B, nb, neq,
                                     maxc, fric_dirs, _lib.ptr(x), _lib.ptr(lam), _lib.ptr(slack), _lib.ptr(nu),
                                     _lib.ptr(dl_dx), _lib.ptr(dM), _lib.ptr(dp), _lib.ptr(dcop), _lib.ptr(dA), _lib.ptr(db),
                                     _lib.stream_ptr(dev))

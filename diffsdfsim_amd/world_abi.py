@@ -21,7 +21,7 @@ FIELDS = [
     ("mass", "pd"), ("inertia", "pd"), ("restitution", "pd"), ("fric", "pd"), ("fext", "pd"),
     ("shape_type", "pi"), ("shape_prm", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
     ("mesh_voff", "pi"), ("mesh_nv", "pi"), ("mesh_foff", "pi"), ("mesh_nf", "pi"),
-    ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"),
+    ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"), ("vgrad", "pd"),
     ("Je", "pd"), ("b_eq", "pd"),
     ("t", "pd"), ("t_end", "pd"), ("dt_try", "pd"), ("last_dt", "pd"), ("dt_use", "pd"),
     ("active", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
@@ -57,7 +57,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF)
         "pose": (B, nb, 7), "vel": (B, nb, 6), "mass": (B, nb), "inertia": (B, nb, 9), "restitution": (B, nb),
         "fric": (B, nb), "fext": (B, nb, 6), "shape_type": (B, nb), "shape_prm": (B, nb, 3), "mesh_id": (B, nb),
         "no_contact": (nb, nb), "mesh_voff": (nmesh,), "mesh_nv": (nmesh,), "mesh_foff": (nmesh,), "mesh_nf": (nmesh,),
-        "verts": (NV, 3), "faces": (NF, 3), "fcent": (NF, 3), "frad": (NF,),
+        "verts": (NV, 3), "faces": (NF, 3), "fcent": (NF, 3), "frad": (NF,), "vgrad": (NV, 3),
         "Je": (B, max(neq, 1), nz), "b_eq": (B, max(neq, 1)),
         "t": (B,), "t_end": (B,), "dt_try": (B,), "last_dt": (B,), "dt_use": (B,),
         "active": (B,), "toc": (B,), "nsub": (B,), "n_active": (1,),
@@ -80,3 +80,26 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF)
             "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc),
         })
     return s
+
+
+ADJ_FIELDS = [
+    ("a_pose", "pd"), ("a_vel", "pd"), ("a_geom", "pd"),
+    ("g_mass", "pd"), ("g_inertia", "pd"), ("g_rest", "pd"), ("g_fric", "pd"), ("g_fext", "pd"), ("g_prm", "pd"),
+    ("cur_slot", "pi"), ("lo_slot", "pi"), ("bw_active", "pi"),
+    ("a_x", "pd"), ("dMblk", "pd"), ("dpvec", "pd"), ("dcop", "pd"), ("cscr", "pd"), ("bw_nc", "pi"),
+]
+
+
+class DssAdjoint(ctypes.Structure):
+    _fields_ = [(n, _P) for n, k in ADJ_FIELDS]
+
+
+def adjoint_shapes(B, nb, maxc, fd):
+    NFc = 3 * (1 + fd // 2) + 8
+    return {
+        "a_pose": (B, nb, 7), "a_vel": (B, nb, 6), "a_geom": (B, 10, maxc),
+        "g_mass": (B, nb), "g_inertia": (B, nb, 9), "g_rest": (B, nb), "g_fric": (B, nb), "g_fext": (B, nb, 6),
+        "g_prm": (B, nb, 3), "cur_slot": (B,), "lo_slot": (B,), "bw_active": (B,),
+        "a_x": (B, 6 * nb), "dMblk": (B, nb, 36), "dpvec": (B, 6 * nb), "dcop": (B, NFc, maxc),
+        "cscr": (B, 20, maxc), "bw_nc": (B,),
+    }

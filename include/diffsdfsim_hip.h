@@ -91,7 +91,8 @@ int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double
                             void *workspace, size_t workspace_bytes, void *stream);
 
 int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *cop, const int *cbody,
-                             const int *nc, int B, int nb, int neq, int maxc, int fric_dirs,
+                             const int *nc, const int *active /* [B] or NULL */,
+                             int B, int nb, int neq, int maxc, int fric_dirs,
                              const double *x, const double *lam, const double *slack, const double *nu,
                              const double *dl_dx,
                              double *dMblk, double *dpvec, double *dcop, double *dA, double *db, void *stream);
@@ -130,6 +131,7 @@ typedef struct DssWorld {
     const int *faces;      /* [NF][3] vertex ids local to the mesh */
     const double *fcent;   /* [NF][3] face centroids, */
     const double *frad;    /* [NF]    max centroid-vertex distance (both pose invariant) */
+    const double *vgrad;   /* [NV][3] d vertex / d shape parameter: box d v_k/d dims_k ; sphere d v/d rad */
     /* equality rows (joints), constant: Je [B][neq][6 nb], right-hand side b_eq [B][neq] (zeros) */
     const double *Je, *b_eq;
     /* per-scene stepping state [B] */
@@ -183,6 +185,34 @@ int dss_step_begin(const DssWorld *W, void *stream);
 int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream);
 /* Contact detection only, at the current pose (World.__init__, world.py:96-100). */
 int dss_find_contacts(const DssWorld *W, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward of the batched stepper: reverse sweep over the tape written by dss_step_attempt
+ * (one record per accepted sub-step).  Replaces what torch.autograd does in the reference for
+ *   LCPFunctionFn.backward                      lcp_physics/lcp/lcp.py:156-213
+ *   the graph of Jc/Jf/M/u assembly              engines.py:36-81, physics3d/world.py:48-101
+ *   Body3D.move / set_p                          physics3d/bodies.py:488-511
+ *   _compute_contacts on the filtered contacts   physics3d/contacts.py:161-214, 262-264
+ * a_pose / a_vel: on entry d(loss)/d(state after the newest unprocessed sub-step), on exit
+ * d(loss)/d(state before the oldest processed one).  a_geom carries the adjoint of the contact
+ * geometry across calls.  g_* accumulate d(loss)/d(parameters) ([B][nb](...), same shapes as the
+ * world's parameter arrays).  cur_slot[s] is the next tape slot to process for scene s, a call
+ * processes it iff cur_slot[s] >= lo_slot[s], then decrements it.
+ * ------------------------------------------------------------------------------------ */
+typedef struct DssAdjoint {
+    double *a_pose, *a_vel, *a_geom;
+    double *g_mass, *g_inertia, *g_rest, *g_fric, *g_fext, *g_prm;
+    int *cur_slot, *lo_slot;
+    /* scratch */
+    int *bw_active;          /* [B] */
+    double *a_x;             /* [B][6 nb] */
+    double *dMblk, *dpvec, *dcop;   /* LCP backward outputs, shapes of Mblk / pvec / cop */
+    double *cscr;            /* [B][20][maxc] per-contact VJP pieces */
+    int *bw_nc;              /* [B] */
+} DssAdjoint;
+
+size_t dss_adjoint_sizeof(void);
+int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,7 @@ def lcp_contact_backward(P, x, lam, slack, nu, dl):
     x, lam, slack, nu, dl = (_c(v) for v in (x, lam, slack, nu, dl))
     dM = np.zeros((B, nb, 6, 6)); dp = np.zeros((B, nz)); dcop = np.zeros((B, NF, maxc))
     dA = np.zeros((B, neq, nz)); db = np.zeros((B, neq))
-    rc = L.dss_lcp_contact_backward(_p(Mblk), _p(A), _p(cop), _p(cbody), _p(nc), B, nb, neq, maxc, fd, _p(x), _p(lam),
+    rc = L.dss_lcp_contact_backward(_p(Mblk), _p(A), _p(cop), _p(cbody), _p(nc), None, B, nb, neq, maxc, fd, _p(x), _p(lam),
                                     _p(slack), _p(nu), _p(dl), _p(dM), _p(dp), _p(dcop), _p(dA), _p(db), None)
     assert rc == 0, rc
     return dM, dp, dcop, dA, db

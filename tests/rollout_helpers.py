@@ -48,3 +48,55 @@ def check_contacts(E, s, body_ref, geom_ref, n_ref, tol=1e-6):
         a = geom[m]; b = geom_ref[:n_ref][mr]
         ia = np.lexsort(np.round(a[:, 3:6], 6).T[::-1]); ib = np.lexsort(np.round(b[:, 3:6], 6).T[::-1])
         assert np.abs(a[ia] - b[ib]).max() < tol, (pair, np.abs(a[ia] - b[ib]).max())
+
+
+def param_grads(E, g, s=0):
+    """Chain the engine-level gradients onto the reference's leaf parameters (dims / radius)."""
+    adj = {k: E.be.to_numpy(v) for k, v in E.adj.items()}
+    out = []
+    nb = len(g["mass"])
+    pi = 0
+    for b in range(nb):
+        if b in g["fixed"]:
+            continue
+        gI = adj["g_inertia"][s, b].reshape(3, 3)
+        m = g["mass"][b]
+        if g["shape_type"][b] == 0:
+            d = g["shape_prm"][b]
+            # custom box inertia m/12 diag(d1^2+d2^2, d0^2+d2^2, d0^2+d1^2) (bodies.py:796-797)
+            dI = np.array([(gI[1, 1] + gI[2, 2]) * 2 * d[0], (gI[0, 0] + gI[2, 2]) * 2 * d[1], (gI[0, 0] + gI[1, 1]) * 2 * d[2]]) * m / 12
+            out.append(adj["g_prm"][s, b] + dI)
+        else:
+            r = g["shape_prm"][b, 0]
+            out.append(np.array(adj["g_prm"][s, b, 0] + 0.8 * m * r * np.trace(gI)))  # 2/5 m r^2 I (bodies.py:993-994)
+        pi += 1
+    return out
+
+
+def check_gradients(E, g, tol=1e-5, s=0):
+    """Reference gradients are bimodal on flat-on-flat contacts (see oracle/gen/gen_rollout_golden.py:
+    `stable_mask` compares two rounding-noise Laplacians); both branches are in the golden and the kernel
+    must reproduce one of them."""
+    got = param_grads(E, g, s)
+    errs = []
+    for key in ("grad_%d", "gradB_%d"):
+        e = 0.0
+        for i, gi in enumerate(got):
+            want = g[key % i]
+            e = max(e, np.abs(gi - want).max() / max(np.abs(want).max(), 1e-300))
+        errs.append(e)
+    assert min(errs) < tol, (errs, got)
+
+
+def rollout_and_sweep(E, nsteps):
+    for _ in range(nsteps):
+        E.step()
+    adj = E._adjoint()
+    ap = np.zeros_like(E.get("pose"))
+    ap[:, :, 4:] = 2 * E.get("pose")[:, :, 4:]     # d/dpos of sum |pos|^2
+    adj["a_pose"][...] = E.be.from_numpy(ap)
+    adj["cur_slot"][...] = E.be.from_numpy((E.get("nsub") - 1).astype(np.int32))
+    adj["lo_slot"][...] = -1      # down to and including the contacts found at construction
+    E.backward_sweep(int(E.get("nsub").max()) + 1)
+
+
