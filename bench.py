@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- sim steps/s (fwd+bwd) of the batched differentiable SDF rigid-body stepper on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU; scenes are independent so every rank
+  steps its own shard of B scenes (weak scaling, no collective inside a step, one trivial gather of the
+  final poses at the end of the timed region).
+Workload = BASELINE.json configs[2]: 1024 scenes x 8 SDF bodies (floor + 7-box stack with friction).
+A "step" = one outer simulation step (World.step(fixed_dt=True)) of the whole batch, forward, plus its
+share of the backward sweep of sum |pos_T|^2; the timed region is K forward steps followed by the full
+reverse sweep through them.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def lcp_algorithmic_bytes(nb, neq, fd, nc_per_scene):
+    """Operands in + results out of one contact-LCP launch, bytes."""
+    ND, NR = fd // 2, fd + 2
+    NF = 3 * (1 + ND) + 8
+    per_scene_fixed = 8 * (36 * nb + 6 * nb + neq * 6 * nb + neq) + 8 * (6 * nb + neq) + 4
+    per_contact = 8 * NF + 8 + 8 * 2 * NR
+    return float(np.sum(per_scene_fixed + per_contact * np.asarray(nc_per_scene, np.float64)))
+
+
+def cpu_baseline(E, n_sample, threads):
+    """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of
+    batch.py / lcp.py) on the operands the GPU just solved, for a bounded sample of scenes."""
+    from oracle import lcp_expand as X
+    from oracle import lcp_oracle as O
+    O.build()
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    P = dict(Mblk=E.get("Mblk"), pvec=E.get("pvec"), A=E.get("Je"), bvec=np.zeros((E.B, E.neq)), cop=E.get("cop"),
+             cbody=E.get("cop_body"), nc=E.be.to_numpy(E.adj["bw_nc"]).copy(), nb=E.nb, neq=E.neq, maxc=E.maxc, fd=E.fd)
+    ncs = P["nc"]
+    pick = np.argsort(ncs)[len(ncs) // 2 - n_sample // 2: len(ncs) // 2 + (n_sample + 1) // 2]   # median-sized scenes
+    nineq_max = int(ncs[pick].max()) * (E.fd + 2)
+    ops = []
+    for s in pick:   # pad to a common nineq with inert rows (h = 1, G = 0) so one batched call covers them
+        Q, p, G, h, A, b, F = X.expand_dense(P, int(s))
+        k = nineq_max - len(h)
+        G = np.vstack([G, np.zeros((k, G.shape[1]))]); h = np.concatenate([h, np.ones(k)])
+        F = np.pad(F, ((0, k), (0, k)))
+        ops.append((Q, p, G, h, A, b, F))
+    Q, p, G, h, A, b, F = (np.stack(o) for o in zip(*ops))
+    t0 = time.time()
+    z, lam, sl, nu, it, st = O.forward(Q, p, G, h, A, b, F, max_iter=10, check_spd=True)
+    O.backward(Q, G, A, F, z, lam, sl, nu, np.ones_like(z))
+    dt = time.time() - t0
+    return dt / len(pick), len(pick), nineq_max
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="scenes per GPU")
+    ap.add_argument("--nbox", type=int, default=7)
+    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from diffsdfsim_amd import _lib, scenes
+    from diffsdfsim_amd.engine import BatchEngine, TorchBackend
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    B, K, Wm = args.batch, args.steps, args.warmup
+    spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=0.2)
+    E = BatchEngine(spec, maxc=160, max_cand=1024, max_pc=32, max_sub=int(1.5 * (K + Wm)) + 16,
+                    backend=TorchBackend(dev))
+
+    def loss_adjoint():
+        adj = E._adjoint()
+        for k in ("a_pose", "a_vel", "a_geom", "g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm"):
+            adj[k].zero_()
+        adj["a_pose"][:, :, 4:] = 2.0 * E.arr["pose"][:, :, 4:]
+        adj["cur_slot"].copy_(E.arr["nsub"] - 1)
+
+    # warm-up: W steps forward + their backward (untimed)
+    att = 0
+    for _ in range(Wm):
+        att += E.step()
+    loss_adjoint()
+    E.adj["lo_slot"].zero_()
+    E.backward_sweep(att)
+    torch.cuda.synchronize()
+
+    # event pairs around every LCP launch of the timed region
+    ev = []
+
+    def fresh_pair():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record()
+        return a, b
+
+    pool = [fresh_pair() for _ in range(4 * K + 64)]
+    torch.cuda.synchronize()
+    lo = E.arr["nsub"].clone()
+    nc_hist = []
+
+    import ctypes
+    L = E.be.lib
+
+    def timed_step():
+        # BatchEngine.step with an event pair per attempt
+        E._check(L.dss_step_begin(ctypes.byref(E.W), E.be.stream()), "dss_step_begin")
+        n, k = E.B, 0
+        while n > 0:
+            a, b = pool[len(ev)]
+            E.W.ev_lcp_start, E.W.ev_lcp_stop = a.cuda_event, b.cuda_event
+            E._check(L.dss_step_attempt(ctypes.byref(E.W), ctypes.c_void_p(E.be.ptr(E.lcp_ws)),
+                                        ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream()), "dss_step_attempt")
+            ev.append((a, b))
+            n = E.be.read_int(E.arr["n_active"])
+            k += 1
+        return k
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    att = 0
+    for _ in range(K):
+        att += timed_step()
+    E.W.ev_lcp_start, E.W.ev_lcp_stop = None, None
+    loss_adjoint()
+    E.adj["lo_slot"].copy_(lo)
+    E.backward_sweep(att)
+    final = E.arr["pose"].clone()
+    if dist is not None:   # "final trivial gather" of the shard results
+        out = [torch.empty_like(final) for _ in range(world)]
+        dist.all_gather(out, final)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        return
+    lcp_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    nc = E.get("nc")
+    algo = lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc)
+    ach = algo / (lcp_ms.mean() * 1e-3) / 1e9
+    overflow = int(E.get("overflow").max())
+    res = {
+        "metric": "sim steps/sec (fwd+bwd), 1024 batched 3D scenes x 8 SDF bodies",
+        "value": world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: floor + %d-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep"
+                               % (args.nbox, B, K),
+                   "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
+                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
+                   "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
+                   "parallelism": "scene-sharded x%d, no collective in step" % world},
+        "roofline": {"bound": "hbm", "kernel": "lcp_contact_forward_kernel<4>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": float(lcp_ms.mean()), "launches": len(lcp_ms), "algorithmic_bytes_per_launch": algo,
+                     "note": "latency-bound (one wavefront per scene, 1 wave/SIMD at B=1024); see DESIGN.md"},
+    }
+    if not args.no_cpu:
+        threads = min(os.cpu_count() or 1, args.cpu_sample)
+        per_scene, ns, nineq = cpu_baseline(E, args.cpu_sample, threads)
+        # per_scene is wall/scene with `threads` scenes in flight; a 1024-scene step needs 1024 * per_scene seconds
+        res["cpu_baseline"] = {"value": 1.0 / (B * per_scene), "unit": "steps/s", "cores": threads, "kind": "port",
+                               "sample": "dense PDIPM LCP fwd+bwd only (oracle/lcp_oracle.c, the reference's algorithm) on the "
+                                         "operands of %d median scenes of this batch (nineq=%d), OpenMP over scenes, scaled to %d "
+                                         "scenes; contact detection not included, so this over-states the CPU" % (ns, nineq, B)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -224,10 +224,12 @@ int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspac
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(assemble_kernel, dim3(W->B), dim3(64), 0, stream, *W);
+    if (W->ev_lcp_start) hipEventRecord((hipEvent_t)W->ev_lcp_start, stream);
     rc = dss_lcp_contact_forward(W->Mblk, W->pvec, W->Je, W->b_eq, W->cop, W->cop_body, W->nc,
                                  W->active, W->B, W->nb, W->neq, W->maxc, W->fric_dirs, 1e-12, 3, W->lcp_max_iter,
                                  W->x, W->lam, W->slack, W->nu, W->lcp_iters, W->lcp_status, lcp_workspace,
                                  lcp_workspace_bytes, stream_);
+    if (W->ev_lcp_stop) hipEventRecord((hipEvent_t)W->ev_lcp_stop, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(integrate_kernel, dim3(W->B), dim3(64), 0, stream, *W);
     NewContacts N;

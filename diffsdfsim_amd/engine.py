@@ -128,7 +128,7 @@ class BatchEngine:
         W.eps, W.tol, W.dt = eps, tol, dt
         W.max_sub = max_sub
         for name, kind in abi.FIELDS:
-            if kind.startswith("p"):
+            if kind in ("pd", "pi", "pb"):
                 setattr(W, name, self.be.ptr(self.arr[name]) if name in self.arr else None)
         self.W = W
         L = self.be.lib

@@ -37,6 +37,7 @@ FIELDS = [
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
     ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"),
+    ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"),
 ]
 
 

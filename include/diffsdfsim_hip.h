@@ -170,6 +170,8 @@ typedef struct DssWorld {
     int max_sub;
     double *tp_pose, *tp_vel, *tp_dt, *tp_x, *tp_lam, *tp_slack, *tp_nu, *tp_abc, *tp_geom;
     int *tp_nc, *tp_body, *tp_face;
+    /* optional hipEvent_t pair recorded around the LCP launch of dss_step_attempt (bench roofline) */
+    void *ev_lcp_start, *ev_lcp_stop;
 } DssWorld;
 
 #define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */

@@ -36,6 +36,8 @@ typedef void *hipStream_t;
 typedef int hipError_t;
 constexpr int hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+typedef void *hipEvent_t;
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 
 namespace dss_emu {
 struct Fiber {
