@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--nbox", type=int, default=7)
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
     args = ap.parse_args()
 
     import torch
@@ -89,7 +90,7 @@ def main():
     _lib.lib()   # fail loudly if the HIP library is missing
 
     B, K, Wm = args.batch, args.steps, args.warmup
-    spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=0.2)
+    spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=args.push)
     # strict_no_pen=False as in the reference's own long-running experiments (optim_sysid.py:104-131): a scene
     # whose penetration cannot be resolved by halving dt proceeds once dt < dt/2^10 (world.py:345-347) instead of
     # retrying forever, which with strict=True stalls the reference as well.
@@ -181,7 +182,7 @@ def main():
         "config": {"workload": "configs[2]: floor + %d-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep"
                                % (args.nbox, B, K),
                    "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
-                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
+                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()), "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
                    "parallelism": "scene-sharded x%d, no collective in step" % world},
         "roofline": {"bound": "hbm", "kernel": "lcp_contact_forward_kernel<4>", "achieved": ach, "peak": HBM_PEAK_GBS,

@@ -181,6 +181,27 @@ class BatchEngine:
         self.attempts += k
         return k
 
+    def step_once(self, max_attempts=4096):
+        """World.step(fixed_dt=False): a single step_dt -- attempts until the first accepted sub-step
+        (world.py:136-139).  Scenes of a batch that accept early simply wait (exact for B = 1)."""
+        L, W = self.be.lib, self.W
+        self._check(L.dss_step_begin(ctypes.byref(W), self.be.stream()), "dss_step_begin")
+        before = self.get("nsub").copy()
+        k = 0
+        while True:
+            self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
+                                           ctypes.c_size_t(self.lcp_ws_bytes), self.be.stream()), "dss_step_attempt")
+            k += 1
+            done = self.get("nsub") > before
+            a = self.arr["active"]
+            a[...] = self.be.from_numpy(np.where(done, 0, self.get("active")).astype(np.int32))
+            if done.all():
+                break
+            if k > max_attempts:
+                raise RuntimeError("step_once did not finish within %d attempts" % max_attempts)
+        self.attempts += k
+        return k
+
     # -- backward ----------------------------------------------------------------------------------
     def _adjoint(self):
         if getattr(self, "adj", None) is None:

@@ -1,0 +1,111 @@
+"""SDF rigid bodies of the 3-D layer (host-side mirror of sdf_physics/physics3d/bodies.py:402-1009).
+
+Same constructor arguments and attributes as the reference (``p``, ``pos``, ``rot``, ``v``, ``mass``, ``verts``,
+``faces``, ``dims``/``rad``, ``restitution``, ``fric_coeff``, ``add_force``, ``add_no_contact``, ``query_sdfs`` is
+on the device side).  Parameters are torch tensors and may require grad; geometry kernels run on the HIP device.
+Only the analytic (custom_mesh / custom_inertia) variants exist; marching-cubes meshes are SURVEY.md §8f N1.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import meshes, world_abi as abi
+from .utils import Defaults3D, get_tensor
+
+
+def _quat_from_euler(v):
+    p, t, s = [0.5 * float(x) for x in v]
+    return [math.cos(p) * math.cos(t) * math.cos(s) + math.sin(p) * math.sin(t) * math.sin(s),
+            math.sin(p) * math.cos(t) * math.cos(s) - math.cos(p) * math.sin(t) * math.sin(s),
+            math.cos(p) * math.sin(t) * math.cos(s) + math.sin(p) * math.cos(t) * math.sin(s),
+            math.cos(p) * math.cos(t) * math.sin(s) - math.sin(p) * math.sin(t) * math.cos(s)]
+
+
+class Body3D:
+    shape_type = None
+
+    def __init__(self, pos, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, **_render_kwargs):
+        pos = get_tensor(pos)
+        if pos.numel() == 3:
+            self.p = torch.cat([pos.new_tensor([1.0, 0, 0, 0]), pos])
+        elif pos.numel() == 6:
+            self.p = torch.cat([pos.new_tensor(_quat_from_euler(pos[:3])), pos[3:]])
+        else:
+            self.p = pos
+        vel = get_tensor(vel)
+        self.v = torch.cat([vel.new_zeros(3), vel]) if vel.numel() == 3 else vel
+        self.mass = get_tensor(mass)
+        self.restitution = get_tensor(restitution)
+        self.fric_coeff = get_tensor(fric_coeff)
+        self.eps = eps
+        self.forces = []
+        self.no_contact = set()
+        self.ang_inertia = self._get_ang_inertia(self.mass)
+
+    rot = property(lambda self: self.p[:4])
+    pos = property(lambda self: self.p[4:])
+
+    def add_force(self, f):
+        self.forces.append(f)
+        f.set_body(self)
+
+    def add_no_contact(self, other):
+        self.no_contact.add(other)
+        other.no_contact.add(self)
+
+    def apply_forces(self, t):
+        if not self.forces:
+            return self.v.new_zeros(6)
+        return sum(f.force(t) for f in self.forces)
+
+
+class SDFBox(Body3D):
+    shape_type = abi.SHAPE_BOX
+
+    def __init__(self, pos, dims, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
+                 custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
+        if not (custom_mesh and custom_inertia):
+            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1); "
+                                      "use custom_mesh=True, custom_inertia=True")
+        self.dims = get_tensor(dims)
+        self.scale = torch.max(self.dims) * 1.5 / 2
+        v, f, tie = meshes.box_mesh(self.dims.detach().cpu().numpy())
+        self.verts_np, self.faces_np, self.vgrad_np = v, f, 0.5 * tie
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return self.dims
+
+    def _get_ang_inertia(self, mass):   # bodies.py:796-797
+        d = self.dims
+        return mass * torch.diag(torch.stack([d[1] ** 2 + d[2] ** 2, d[0] ** 2 + d[2] ** 2, d[0] ** 2 + d[1] ** 2])) / 12
+
+
+class SDFSphere(Body3D):
+    shape_type = abi.SHAPE_SPHERE
+
+    def __init__(self, pos, rad, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
+                 custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
+        if not (custom_mesh and custom_inertia):
+            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1)")
+        self.rad = get_tensor(rad)
+        self.scale = self.rad * 1.5
+        uv, uf = meshes.icosphere(4)
+        self.verts_np, self.faces_np, self.vgrad_np = uv * float(self.rad), uf, uv
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return torch.cat([self.rad.reshape(1), self.rad.new_zeros(2)])
+
+    def _get_ang_inertia(self, mass):   # bodies.py:993-994
+        return 2.0 / 5.0 * mass * self.rad ** 2 * torch.eye(3, dtype=torch.float64)

@@ -1,0 +1,180 @@
+"""World3D / BatchWorld3D / run_world -- the reference's world surface on top of the HIP engine.
+
+Mirrors sdf_physics/physics3d/world.py:32-205 and lcp_physics/physics/world.py:38-139 for what demos/ and
+experiments/ touch: constructor keywords, ``step(fixed_dt)``, ``t``, ``dt``, ``bodies``, ``contacts``,
+``trajectory``, ``run_world``.  One outer step is ONE torch.autograd node (``_StepFn``): its forward runs the
+attempt loop of the device engine, its backward runs the reverse tape sweep of csrc/step_bwd.hip, so
+``loss.backward()`` reaches body parameters (dims, rad, mass, fric_coeff, restitution, forces) and the initial
+state exactly as it does through the reference's Python graph.  The adjoint of the contact geometry, which
+crosses step boundaries (contacts found at the end of step k enter the LCP of step k+1), is carried inside the
+engine between consecutive backward nodes.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import world_abi as abi
+from ..engine import BatchEngine, TorchBackend
+from .utils import Defaults3D
+
+PARAMS = ("mass", "inertia", "restitution", "fric", "fext", "shape_prm")
+
+
+class _StepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm):
+        E = world.engine
+        for name, t in zip(("pose", "vel") + PARAMS, (pose, vel, mass, inertia.reshape(E.B, E.nb, 9), rest, fric, fext, prm)):
+            E.arr[name].copy_(t.detach())
+        nsub0 = E.arr["nsub"].clone()
+        att = E.step() if fixed_dt else E.step_once()
+        ctx.world, ctx.nsub0, ctx.att = world, nsub0, att
+        ctx.index = world._n_nodes
+        world._n_nodes += 1
+        return E.arr["pose"].clone(), E.arr["vel"].clone()
+
+    @staticmethod
+    def backward(ctx, g_pose, g_vel):
+        w = ctx.world
+        E = w.engine
+        adj = E._adjoint()
+        if ctx.index == w._n_nodes - 1 or w._bw_next != ctx.index:   # newest node: start a fresh reverse sweep
+            adj["a_geom"].zero_()
+            adj["cur_slot"].copy_(E.arr["nsub"] - 1)
+        w._bw_next = ctx.index - 1
+        for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm"):
+            adj[k].zero_()
+        adj["a_pose"].copy_(g_pose)
+        adj["a_vel"].copy_(g_vel)
+        first = ctx.index == 0
+        adj["lo_slot"].copy_(ctx.nsub0 - (1 if first else 0))   # slot -1: contacts found at construction
+        E.backward_sweep(ctx.att + (1 if first else 0))
+        return (None, None, adj["a_pose"].clone(), adj["a_vel"].clone(), adj["g_mass"].clone(),
+                adj["g_inertia"].reshape(E.B, E.nb, 3, 3).clone(), adj["g_rest"].clone(), adj["g_fric"].clone(),
+                adj["g_fext"].clone(), adj["g_prm"].clone())
+
+
+class BatchWorld3D:
+    """B independent scenes stepped in lock step on one HIP device (the capability BASELINE.json adds).
+
+    ``spec``: BatchEngine spec (see diffsdfsim_amd.scenes).  ``params``: optional dict of torch tensors
+    (mass [B,nb], inertia [B,nb,3,3], restitution, fric [B,nb], fext [B,nb,6], shape_prm [B,nb,3]) that may
+    require grad; ``pose`` / ``vel`` are the current state tensors (autograd-connected)."""
+
+    def __init__(self, spec, params=None, dt=Defaults3D.DT, eps=Defaults3D.EPSILON, tol=Defaults3D.TOL,
+                 fric_dirs=Defaults3D.FRIC_DIRS, strict_no_penetration=True, time_of_contact_diff=True, device=None,
+                 max_substeps=1024, maxc=96, max_cand=1024, max_pc=32):
+        dev = torch.device(device) if device is not None else Defaults3D.DEVICE
+        self.engine = BatchEngine(spec, dt=dt, eps=eps, tol=tol, fric_dirs=fric_dirs, maxc=maxc, max_cand=max_cand,
+                                  max_pc=max_pc, max_sub=max_substeps, strict_no_pen=strict_no_penetration,
+                                  toc_diff=time_of_contact_diff, backend=TorchBackend(dev))
+        E = self.engine
+        self.device, self.dt = dev, dt
+        self.B, self.nb = E.B, E.nb
+        self.params = {k: E.arr[k].clone().reshape((E.B, E.nb, 3, 3) if k == "inertia" else E.arr[k].shape) for k in PARAMS}
+        for k, v in (params or {}).items():
+            self.params[k] = v
+        self.pose, self.vel = E.arr["pose"].clone(), E.arr["vel"].clone()
+        self._n_nodes, self._bw_next = 0, -1
+        self.trajectory = []
+
+    @property
+    def t(self):
+        return self.engine.get("t")
+
+    def step(self, fixed_dt=True):
+        P = self.params
+        to = lambda x: x.to(self.device)
+        self.pose, self.vel = _StepFn.apply(self, fixed_dt, to(self.pose), to(self.vel), to(P["mass"]), to(P["inertia"]),
+                                            to(P["restitution"]), to(P["fric"]), to(P["fext"]), to(P["shape_prm"]))
+        return self.engine.get("nc") > 0
+
+    def contact_pairs(self, s=0):
+        nc = int(self.engine.get("nc")[s])
+        return [tuple(r) for r in self.engine.get("c_body")[s][:, :nc].T]
+
+
+class World3D(BatchWorld3D):
+    """Drop-in for ``sdf_physics.physics3d.world.World3D`` (one scene = batch of one)."""
+
+    def __init__(self, bodies, constraints=[], dt=Defaults3D.DT, engine=Defaults3D.ENGINE,
+                 contact_callback=Defaults3D.CONTACT, eps=Defaults3D.EPSILON, tol=Defaults3D.TOL,
+                 fric_dirs=Defaults3D.FRIC_DIRS, post_stab=Defaults3D.POST_STABILIZATION, strict_no_penetration=True,
+                 time_of_contact_diff=True, stop_contact_grad=False, stop_friction_grad=False, detach_contact_b2=False,
+                 device=None, max_substeps=1024):
+        if post_stab or stop_contact_grad or stop_friction_grad or detach_contact_b2:
+            raise NotImplementedError("post_stab / stop_*_grad / detach_contact_b2 are not built on the HIP path yet")
+        self.bodies = bodies
+        self.vec_len = 6
+        nb = len(bodies)
+        idx = {id(b): i for i, b in enumerate(bodies)}
+        rows = []
+        for j in constraints:
+            J1, _ = j.J()
+            blk = torch.zeros(J1.shape[0], 6 * nb, dtype=torch.float64)
+            blk[:, 6 * idx[id(j.body1)]:6 * idx[id(j.body1)] + 6] = J1
+            rows.append(blk)
+        Je = torch.cat(rows).numpy()[None] if rows else np.zeros((1, 0, 6 * nb))
+        nocon = np.zeros((nb, nb), np.uint8)
+        for i, b in enumerate(bodies):
+            for o in b.no_contact:
+                nocon[i, idx[id(o)]] = 1
+        st = lambda f: torch.stack([f(b) for b in bodies])[None]
+        self._ptensors = lambda t: dict(
+            mass=st(lambda b: b.mass.reshape(())), inertia=st(lambda b: b.ang_inertia),
+            restitution=st(lambda b: b.restitution.reshape(())), fric=st(lambda b: b.fric_coeff.reshape(())),
+            fext=st(lambda b: b.apply_forces(t)), shape_prm=st(lambda b: b.shape_prm()))
+        P = self._ptensors(0.0)
+        npd = lambda x: x.detach().cpu().numpy()
+        spec = dict(pose=npd(st(lambda b: b.p)), vel=npd(st(lambda b: b.v)), mass=npd(P["mass"]), inertia=npd(P["inertia"]),
+                    restitution=npd(P["restitution"]), fric=npd(P["fric"]), fext=npd(P["fext"]),
+                    shape_type=np.array([[b.shape_type for b in bodies]], np.int32), shape_prm=npd(P["shape_prm"]),
+                    mesh_id=np.arange(nb, dtype=np.int32)[None], meshes=[(b.verts_np, b.faces_np) for b in bodies],
+                    mesh_vgrad=[b.vgrad_np for b in bodies], Je=Je, no_contact=nocon)
+        maxc = 32 * max(1, nb - 1)
+        super().__init__(spec, None, dt, eps, tol, fric_dirs, strict_no_penetration, time_of_contact_diff, device,
+                         max_substeps, maxc=maxc)
+        self.pose = st(lambda b: b.p).to(self.device)      # keep the graph to leaf poses / velocities
+        self.vel = st(lambda b: b.v).to(self.device)
+        self.eps, self.tol, self.fric_dirs = eps, tol, fric_dirs
+        self._t = 0.0
+        self._sync_bodies()
+
+    t = property(lambda self: self._t)
+
+    def _sync_bodies(self):
+        for i, b in enumerate(self.bodies):
+            b.p, b.v = self.pose[0, i], self.vel[0, i]
+
+    @property
+    def contacts(self):
+        """[((normal, p1, p2, penetration), body1, body2)] as in the reference (values; detached)."""
+        E = self.engine
+        nc = int(E.get("nc")[0])
+        g, b = E.get("c_geom")[0], E.get("c_body")[0]
+        out = []
+        for c in range(nc):
+            tt = lambda a: torch.tensor(a.copy())
+            out.append(((tt(g[0:3, c]), tt(g[3:6, c]), tt(g[6:9, c]), tt(g[9, c])), int(b[0, c]), int(b[1, c])))
+        return out
+
+    def step(self, fixed_dt=False):
+        self.params = self._ptensors(self._t)      # forces may depend on time (ExternalForce3D.force_func)
+        had = bool(BatchWorld3D.step(self, fixed_dt)[0])
+        self._t = float(self.engine.get("t")[0])
+        self._sync_bodies()
+        self.trajectory.append((self._t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), None, None))
+        return had
+
+    def get_v(self):
+        return self.vel[0].reshape(-1)
+
+
+def run_world(world, fixed_dt=False, animation_dt=None, run_time=10, print_time=True, scene=None, recorder=None, **_render):
+    """sdf_physics/physics3d/world.py:113-205 without the pyrender viewer (rendering is out of scope)."""
+    start = time.time()
+    while world.t < run_time:
+        world.step(fixed_dt=fixed_dt)
+        if print_time:
+            print("\r {} / {} ".format(world.t, time.time() - start), end="")

@@ -1,0 +1,58 @@
+"""GPU: the reference-shaped Python surface (World3D / bodies / constraints / forces / autograd) end to end."""
+import numpy as np
+import pytest
+import torch
+
+import rollout_helpers as R
+
+pytestmark = pytest.mark.gpu
+
+
+def build_sphere_world(g, toc):
+    from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, SDFSphere, TotalConstraint3D, World3D
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=float(g["restitution"][0]), fric_coeff=float(g["fric"][0]))
+    rad = torch.tensor(float(g["param_0"]), dtype=torch.float64, requires_grad=True)
+    ball = SDFSphere(g["pose0"][1, 4:].tolist(), rad, vel=g["vel0"][1].tolist(), restitution=float(g["restitution"][1]),
+                     fric_coeff=float(g["fric"][1]))
+    ball.add_force(Gravity3D())
+    w = World3D([floor, ball], [TotalConstraint3D(floor)], time_of_contact_diff=toc)
+    return w, floor, ball, rad
+
+
+def test_world3d_rollout_and_gradient_match_reference():
+    """Same scene as tests/golden/rollout_sphere_notoc.npz built through the public API; the floor mesh comes from
+    diffsdfsim_amd.meshes (1 ulp from the reference's torch.linspace), so trajectories agree to ~1e-9, not 1e-12."""
+    g = R.load_rollout("rollout_sphere_notoc")
+    w, floor, ball, rad = build_sphere_world(g, toc=False)
+    for _ in range(24):
+        w.step(fixed_dt=True)
+    k = len(g["traj_t"]) - 1
+    assert abs(w.t - float(g["t_final"])) < 1e-12
+    assert np.abs(ball.p.detach().cpu().numpy() - g["traj_p"][k][1]).max() < 1e-7
+    assert np.abs(ball.v.detach().cpu().numpy() - g["traj_v"][k][1]).max() < 1e-7
+    loss = sum((b.pos ** 2).sum() for b in (floor, ball))
+    assert abs(float(loss) - float(g["loss"])) < 1e-7
+    loss.backward()
+    assert abs(float(rad.grad) - float(g["grad_0"])) < 1e-5 * abs(float(g["grad_0"])) + 1e-9, (rad.grad, g["grad_0"])
+
+
+def test_world3d_step_without_fixed_dt_and_run_world():
+    from diffsdfsim_amd.physics3d import run_world
+    g = R.load_rollout("rollout_sphere_notoc")
+    w, floor, ball, rad = build_sphere_world(g, toc=True)
+    run_world(w, fixed_dt=False, run_time=0.2, print_time=False)
+    assert w.t >= 0.2 and len(w.trajectory) >= 6
+    assert isinstance(w.contacts, list)
+
+
+def test_batchworld3d_parameter_gradients_flow():
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.physics3d import BatchWorld3D
+    spec = scenes.sphere_drop(8, seed=3, floor_dims=(4.0, 1.0, 4.0))
+    prm = torch.tensor(spec["shape_prm"], dtype=torch.float64, requires_grad=True)
+    w = BatchWorld3D(spec, params=dict(shape_prm=prm), time_of_contact_diff=False, max_substeps=256)
+    for _ in range(30):
+        w.step()
+    (w.pose[:, :, 4:] ** 2).sum().backward()
+    gr = prm.grad[:, 1, 0]
+    assert torch.isfinite(gr).all() and (gr != 0).any()
