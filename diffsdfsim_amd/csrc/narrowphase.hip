@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
             cface[slot] = f;
             for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
         }
-        if (ncand > MC) { over = 1; ncand = MC; }
+        if (ncand > MC) { over |= 1; ncand = MC; }
     }
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return; }
     __syncthreads();
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
         const int slot = compact_slot(flag, ncon, S);
         if (slot >= 0) { kface[slot] = cface[k]; for (int i = 0; i < 3; ++i) CB(15 + i, slot) = abc[i]; }
     }
-    if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) W.overflow[sc] = 1; } return; }
+    if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) atomicOr(W.overflow + sc, over); } return; }
     __syncthreads();
 
     // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
                 }
             }
             __syncthreads();
-            if (m > 1024) { over = 1; m = 1024; }
+            if (m > 1024) { over |= 2; m = 1024; }
             cluster_hull(S, m, W.eps);
             for (int j = tid; j < m; j += NT) if (S.hflag[j]) cstate[S.hidx[j]] = -2;
             __syncthreads();
@@ -586,9 +586,9 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
                 pg[(size_t)9 * MP + slot] = pen;
             }
         }
-        if (nout > MP) { over = 1; nout = MP; }
+        if (nout > MP) { over |= 4; nout = MP; }
     }
-    if (tid == 0) { *pc_count = nout; if (over) W.overflow[sc] = 1; }
+    if (tid == 0) { *pc_count = nout; if (over) atomicOr(W.overflow + sc, over); }
 #undef CB
 }
 
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *n
                 off += cnt;
             }
     if (lane == 0) {
-        if (off > MX) { W.overflow[sc] = 1; off = MX; }
+        if (off > MX) { atomicOr(W.overflow + sc, 8); off = MX; }
         nc_out[sc] = off;
     }
 }

@@ -57,7 +57,7 @@ class Body3D:
 
     def apply_forces(self, t):
         if not self.forces:
-            return self.v.new_zeros(6)
+            return torch.zeros(6, dtype=torch.float64)
         return sum(f.force(t) for f in self.forces)
 
 
@@ -98,7 +98,7 @@ class SDFSphere(Body3D):
         self.rad = get_tensor(rad)
         self.scale = self.rad * 1.5
         uv, uf = meshes.icosphere(4)
-        self.verts_np, self.faces_np, self.vgrad_np = uv * float(self.rad), uf, uv
+        self.verts_np, self.faces_np, self.vgrad_np = uv * float(self.rad.detach()), uf, uv
         super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
 
     verts = property(lambda self: torch.as_tensor(self.verts_np))

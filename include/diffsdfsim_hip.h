@@ -158,7 +158,7 @@ typedef struct DssWorld {
     /* narrow phase scratch */
     int *ovl;                /* [B][nb][nb] overlap flags */
     int *invalid;            /* [B] penetration > tol found in this attempt */
-    int *overflow;           /* [B] a capacity (max_cand / max_pc / maxc) was exceeded */
+    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
     int *pc_face;            /* [B][npairs][max_pc] */
     double *pc_abc;          /* [B][npairs][3][max_pc] */

@@ -171,6 +171,7 @@ inline unsigned long long __ballot(int pred)
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
