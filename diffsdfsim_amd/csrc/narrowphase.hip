@@ -65,43 +65,84 @@ __device__ inline void to_frame(const BodyG<double> &a, const BodyG<double> &b, 
     quat_apply_inv(b.q, r, o);
 }
 
+
+// axis-aligned box, in the body frame of `a`, that contains body b's query cube [-s,s]^3 (+ margin)
+struct Region { double c[3], e[3]; };
+__device__ inline void region_of(const BodyG<double> &a, const BodyG<double> &b, double margin, Region &r)
+{
+    double Ra[9], Rb[9];
+    quat_to_mat(a.q, Ra);
+    quat_to_mat(b.q, Rb);
+    const double d[3] = {b.pos[0] - a.pos[0], b.pos[1] - a.pos[1], b.pos[2] - a.pos[2]};
+    const double s = b.shape.scale;
+    for (int i = 0; i < 3; ++i) {
+        r.c[i] = Ra[i] * d[0] + Ra[3 + i] * d[1] + Ra[6 + i] * d[2];          // R_a^T (x_b - x_a)
+        double e = 0.0;
+        for (int j = 0; j < 3; ++j) e += fabs(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);   // |R_a^T R_b|
+        r.e[i] = s * e * (1.0 + 1e-9) + margin;
+    }
+}
+__device__ inline bool box_hits(const Region &r, const double *bx)
+{
+    for (int i = 0; i < 3; ++i)
+        if (bx[i] > r.c[i] + r.e[i] || bx[3 + i] < r.c[i] - r.e[i]) return false;
+    return true;
+}
+
 // ---- _overlap ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
 {
-    const int nup = W.nb * (W.nb - 1) / 2;
+    const int nup = W.nb * (W.nb - 1) / 2, np = npairs_of(W.nb);
     const int sc = blockIdx.x / nup, up = blockIdx.x % nup, tid = threadIdx.x;
     if (!W.active[sc]) return;
     int i = 0, rem = up;
     while (rem >= W.nb - 1 - i) { rem -= W.nb - 1 - i; ++i; }
     const int j = i + 1 + rem;
     int *flag = W.ovl + ((size_t)sc * W.nb + i) * W.nb + j;
-    if (W.no_contact[i * W.nb + j]) { if (tid == 0) *flag = 0; return; }
-    BodyD A, Bd;
-    load_body(W, sc, i, A);
-    load_body(W, sc, j, Bd);
-    int ok = 1;
-    for (int dir = 0; dir < 2 && ok; ++dir) {
-        const BodyD &src = dir ? Bd : A, &dst = dir ? A : Bd;
-        const double s = dst.g.shape.scale;
-        int found = 0;
-        for (int base = 0; base < src.nv && !found; base += NT) {
-            int hit = 0;
-            const int v = base + tid;
-            if (v < src.nv) {
-                double p[3];
-                to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
-                hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+    const int dp_ij = i * (W.nb - 1) + (j - 1), dp_ji = j * (W.nb - 1) + i;
+    int ok = !W.no_contact[i * W.nb + j];
+    if (ok) {
+        BodyD A, Bd;
+        load_body(W, sc, i, A);
+        load_body(W, sc, j, Bd);
+        for (int dir = 0; dir < 2 && ok; ++dir) {
+            const BodyD &src = dir ? Bd : A, &dst = dir ? A : Bd;
+            const double s = dst.g.shape.scale;
+            Region reg;
+            region_of(src.g, dst.g, 1e-9, reg);
+            const double *vbox = W.vch_box + (size_t)W.mesh_vch_off[src.mesh] * 6;
+            int found = 0;
+            for (int base = 0; base < src.nv && !found; base += NT) {
+                if (!box_hits(reg, vbox + (size_t)(base / NT) * 6)) continue;   // uniform: no vertex of this run can be inside
+                int hit = 0;
+                const int v = base + tid;
+                if (v < src.nv) {
+                    double p[3];
+                    to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
+                    hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+                }
+                found = __syncthreads_or(hit);
             }
-            found = __syncthreads_or(hit);
+            ok = found;
         }
-        ok = found;
     }
-    if (tid == 0) *flag = ok;
+    if (tid == 0) {
+        *flag = ok;
+        if (ok) {
+            const int at = atomicAdd(W.n_pairs, 2);
+            W.pair_list[at] = sc * np + dp_ij;
+            W.pair_list[at + 1] = sc * np + dp_ji;
+        } else {
+            W.pc_count[(size_t)sc * np + dp_ij] = 0;
+            W.pc_count[(size_t)sc * np + dp_ji] = 0;
+        }
+    }
 }
 
 // ---- workgroup scratch ------------------------------------------------------------------------
 struct Scratch {
     int wave_tot[NT / 64];
+    int vote[2][NT / 64];
     int red_i[NT];
     double red_d[NT];
     double hp[3 * 1024];   // cluster points for the hull
@@ -336,17 +377,15 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
 }
 
 // ---- the narrow phase -------------------------------------------------------------------------
-__global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
+__device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
 {
-    __shared__ Scratch S;
+#define STAMP(i) do { if (W.dbg_stamps && threadIdx.x == 0) W.dbg_stamps[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
+    STAMP(0);
     const int np = npairs_of(W.nb);
-    const int sc = blockIdx.x / np, dp = blockIdx.x % np, tid = threadIdx.x;
-    if (!W.active[sc]) return;
+    const int sc = item / np, dp = item % np, tid = threadIdx.x;
     int a, b;
     pair_of(dp, W.nb, a, b);
     int *pc_count = W.pc_count + (size_t)sc * np + dp;
-    const int lo = a < b ? a : b, hi = a < b ? b : a;
-    if (W.no_contact[a * W.nb + b] || !W.ovl[((size_t)sc * W.nb + lo) * W.nb + hi]) { if (tid == 0) *pc_count = 0; return; }
     BodyD A, Bd;
     load_body(W, sc, a, A);
     load_body(W, sc, b, Bd);
@@ -368,7 +407,11 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
 
     // ---- 1. candidate faces (contacts.py:44-52) in ascending face order ------------------------
     int ncand = 0, over = 0;
+    Region reg;
+    region_of(A.g, Bd.g, 1e-9, reg);
+    const double *fbox = W.fch_box + (size_t)W.mesh_fch_off[A.mesh] * 6;
     for (int base = 0; base < A.nf; base += NT) {
+        if (!box_hits(reg, fbox + (size_t)(base / NT) * 6)) continue;   // uniform: no centroid of this run is inside b's cube
         const int f = base + tid;
         int flag = 0;
         double pqr[3][3];
@@ -406,54 +449,77 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
     }
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return; }
     __syncthreads();
+    STAMP(1);
 
     // ---- 2. Frank-Wolfe (contacts.py:57-82) -----------------------------------------------------
-    for (int k = tid; k < ncand; k += NT) {
+    // The first candidate of every thread lives in registers for the whole loop (typical pairs have fewer
+    // candidates than threads); further ones stream through the L2-resident scratch.  One barrier per
+    // iteration: the two early-exit votes travel as ballots through a parity-double-buffered LDS word.
+    struct Cand { double pqr[9], x[3], abc[3]; };
+    auto load_c = [&](Cand &c, int k) {
+        for (int i = 0; i < 9; ++i) c.pqr[i] = CB(i, k);
+        for (int i = 0; i < 3; ++i) { c.x[i] = CB(9 + i, k); c.abc[i] = CB(12 + i, k); }
+    };
+    auto store_c = [&](const Cand &c, int k) {
+        for (int i = 0; i < 3; ++i) { CB(9 + i, k) = c.x[i]; CB(12 + i, k) = c.abc[i]; }
+    };
+    auto init_c = [&](Cand &c) {
         double best = INFINITY; int bi = 0;
         for (int v = 0; v < 3; ++v) {
-            const double p[3] = {CB(3 * v, k), CB(3 * v + 1, k), CB(3 * v + 2, k)};
             double phi, g[3];
-            query_sdf(Bd.g.shape, p, phi, g, false);
+            query_sdf(Bd.g.shape, c.pqr + 3 * v, phi, g, false);
             if (phi < best) { best = phi; bi = v; }
         }
-        for (int i = 0; i < 3; ++i) { CB(9 + i, k) = CB(3 * bi + i, k); CB(12 + i, k) = (i == bi) ? 1.0 : 0.0; }
-    }
+        for (int i = 0; i < 3; ++i) { c.x[i] = c.pqr[3 * bi + i]; c.abc[i] = (i == bi) ? 1.0 : 0.0; }
+    };
+    // NOTE the reference forms gamma as python_float * bool_tensor (contacts.py:72-73), which torch
+    // promotes to float32: the step sizes, and 1 - gamma, are float32-rounded.  Replicated bit for bit.
+    auto eval_c = [&](const Cand &c, int iter, float &gm, int &bi, int &pen) {
+        double phi, g[3];
+        query_sdf(Bd.g.shape, c.x, phi, g, true);
+        double bestd = INFINITY; bi = 0;
+        for (int v = 0; v < 3; ++v) {
+            const double d = c.pqr[3 * v] * g[0] + c.pqr[3 * v + 1] * g[1] + c.pqr[3 * v + 2] * g[2];
+            if (d < bestd) { bestd = d; bi = v; }
+        }
+        const double impr = (c.x[0] - c.pqr[3 * bi]) * g[0] + (c.x[1] - c.pqr[3 * bi + 1]) * g[1] + (c.x[2] - c.pqr[3 * bi + 2]) * g[2];
+        gm = (fabs(impr) > W.tol) ? (float)(2.0 / (iter + 2.0)) : 0.0f;
+        pen = phi < -W.tol;
+    };
+    auto apply_c = [&](Cand &c, float g32, int bi) {
+        const double gm = (double)g32, om = (double)(1.0f - g32);
+        for (int i = 0; i < 3; ++i) { c.x[i] = om * c.x[i] + gm * c.pqr[3 * bi + i]; c.abc[i] *= om; }
+        c.abc[bi] += gm;
+    };
+    Cand r0;
+    const bool has0 = tid < ncand;
+    if (has0) { load_c(r0, tid); init_c(r0); }
+    for (int k = tid + NT; k < ncand; k += NT) { Cand c; load_c(c, k); init_c(c); store_c(c, k); }
     __syncthreads();
     for (int iter = 0; iter < 32; ++iter) {
-        // NOTE the reference forms gamma as python_float * bool_tensor (contacts.py:72-73), which torch
-        // promotes to float32: the step sizes, and 1 - gamma, are float32-rounded.  Replicated bit for bit.
         float gam[MAX_CPT]; int ind[MAX_CPT];
-        int any_pen = 0, all_zero = 1, q = 0;
-        for (int k = tid; k < ncand; k += NT, ++q) {
-            const double x[3] = {CB(9, k), CB(10, k), CB(11, k)};
-            double phi, g[3];
-            query_sdf(Bd.g.shape, x, phi, g, true);
-            double bestd = INFINITY; int bi = 0;
-            for (int v = 0; v < 3; ++v) {
-                const double d = CB(3 * v, k) * g[0] + CB(3 * v + 1, k) * g[1] + CB(3 * v + 2, k) * g[2];
-                if (d < bestd) { bestd = d; bi = v; }
-            }
-            const double impr = (x[0] - CB(3 * bi, k)) * g[0] + (x[1] - CB(3 * bi + 1, k)) * g[1] + (x[2] - CB(3 * bi + 2, k)) * g[2];
-            const float gm = (fabs(impr) > W.tol) ? (float)(2.0 / (iter + 2.0)) : 0.0f;
-            gam[q] = gm; ind[q] = bi;
-            if (gm != 0.0f) all_zero = 0;
-            if (phi < -W.tol) any_pen = 1;
+        int any_pen = 0, moving = 0, q = 0, pen;
+        if (has0) { eval_c(r0, iter, gam[0], ind[0], pen); any_pen |= pen; moving |= gam[0] != 0.0f; }
+        q = 1;
+        for (int k = tid + NT; k < ncand; k += NT, ++q) {
+            Cand c; load_c(c, k);
+            eval_c(c, iter, gam[q], ind[q], pen);
+            any_pen |= pen; moving |= gam[q] != 0.0f;
         }
-        const int stop_a = __syncthreads_and(all_zero), stop_b = __syncthreads_or(any_pen);
-        if (stop_a || stop_b) break;
-        q = 0;
-        for (int k = tid; k < ncand; k += NT, ++q) {
-            const double gm = (double)gam[q], om = (double)(1.0f - gam[q]);
-            const int bi = ind[q];
-            for (int i = 0; i < 3; ++i) {
-                CB(9 + i, k) = om * CB(9 + i, k) + gm * CB(3 * bi + i, k);
-                CB(12 + i, k) *= om;
-            }
-            CB(12 + bi, k) += gm;
-        }
+        const unsigned long long bm = __ballot(moving), bp = __ballot(any_pen);
+        if ((tid & 63) == 0) S.vote[iter & 1][tid >> 6] = (bm != 0ull ? 1 : 0) | (bp != 0ull ? 2 : 0);
+        __syncthreads();
+        int vote = 0;
+        for (int w = 0; w < NT / 64; ++w) vote |= S.vote[iter & 1][w];
+        if (!(vote & 1) || (vote & 2)) break;   // all gamma == 0, or a penetrating point (contacts.py:74-77)
+        if (has0) apply_c(r0, gam[0], ind[0]);
+        q = 1;
+        for (int k = tid + NT; k < ncand; k += NT, ++q) { Cand c; load_c(c, k); apply_c(c, gam[q], ind[q]); store_c(c, k); }
     }
+    if (has0) store_c(r0, tid);
     __syncthreads();
 
+    STAMP(2);
     // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) -------------------
     double qrel[4];
     {
@@ -488,6 +554,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
     if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) atomicOr(W.overflow + sc, over); } return; }
     __syncthreads();
 
+    STAMP(3);
     // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
     int bad = 0;
     for (int k = tid; k < ncon; k += NT) {
@@ -505,6 +572,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
         return;
     }
 
+    STAMP(4);
     // ---- 5. filter: greedy normal clusters, hull of each (contacts.py:97-158) -------------------
     int nkeep = 0;
     if (ncon <= 1) {
@@ -547,6 +615,7 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
         nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
     }
 
+    STAMP(5);
     // ---- 6. final geometry of the kept contacts, in ascending face order --------------------------
     // (the reference emits cluster by cluster in Qhull's vertex order, which is implementation
     //  defined; contact sets of a pair are compared as sets)
@@ -589,7 +658,20 @@ __global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
         if (nout > MP) { over |= 4; nout = MP; }
     }
     if (tid == 0) { *pc_count = nout; if (over) atomicOr(W.overflow + sc, over); }
+    STAMP(6);
+#undef STAMP
 #undef CB
+}
+
+// persistent: every workgroup walks the active-pair list with a grid stride
+__global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
+{
+    __shared__ Scratch S;
+    const int n = W.n_pairs[0];
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        __syncthreads();
+        narrow_pair(W, S, W.pair_list[it]);
+    }
 }
 
 // ---- gather the per-pair lists into the scene's contact list in callback order ------------------
@@ -633,8 +715,11 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
 {
     if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
+    hipMemsetAsync(W.n_pairs, 0, sizeof(int), stream);
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
-    hipLaunchKernelGGL(narrowphase_kernel, dim3(W.B * np), dim3(NT), 0, stream, W);
+    // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
+    const int grid = W.B * np < 256 * 3 ? W.B * np : 256 * 3;
+    hipLaunchKernelGGL(narrowphase_kernel, dim3(grid), dim3(NT), 0, stream, W);
     hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }

@@ -51,6 +51,9 @@ class TorchBackend:
         return int(t.item())
 
 
+CHUNK = 256   # must equal NT of narrowphase.hip
+
+
 def default_vgrad(shape_type, prm, verts):
     """d vertex / d shape parameter of the analytic meshes (bodies.py:803-813 box, :1004-1007 sphere).
 
@@ -66,6 +69,8 @@ def default_vgrad(shape_type, prm, verts):
 def mesh_table(meshes, vgrads=None):
     """Concatenate (verts, faces) meshes; precompute pose-invariant face centroids and radii."""
     voff, nv, foff, nf, V, F, C, R = [], [], [], [], [], [], [], []
+    fch, vch, fch_off, vch_off = [], [], [], []
+    nfc = nvc = 0
     vo = fo = 0
     for verts, faces in meshes:
         verts = np.asarray(verts, np.float64); faces = np.asarray(faces, np.int64)
@@ -75,8 +80,18 @@ def mesh_table(meshes, vgrads=None):
         rad = np.linalg.norm(cen[:, None, :] - tri, axis=2).max(axis=1)
         V.append(verts); F.append(faces.astype(np.int32)); C.append(cen); R.append(rad)
         vo += len(verts); fo += len(faces)
+        # culling boxes of runs of 256 consecutive faces / vertices (narrowphase.hip)
+        fch_off.append(nfc); vch_off.append(nvc)
+        for k in range(0, len(faces), CHUNK):
+            c, r = cen[k:k + CHUNK], rad[k:k + CHUNK, None]
+            fch.append(np.concatenate([(c - r).min(0), (c + r).max(0)]))
+        for k in range(0, len(verts), CHUNK):
+            fv = verts[k:k + CHUNK]
+            vch.append(np.concatenate([fv.min(0), fv.max(0)]))
+        nfc, nvc = len(fch), len(vch)
     i32 = lambda x: np.asarray(x, np.int32)
     out = dict(mesh_voff=i32(voff), mesh_nv=i32(nv), mesh_foff=i32(foff), mesh_nf=i32(nf),
+               fch_box=np.stack(fch), vch_box=np.stack(vch), mesh_fch_off=i32(fch_off), mesh_vch_off=i32(vch_off),
                verts=np.concatenate(V), faces=np.concatenate(F), fcent=np.concatenate(C), frad=np.concatenate(R))
     out["vgrad"] = np.concatenate([np.asarray(g, np.float64) for g in vgrads]) if vgrads is not None else np.zeros_like(out["verts"])
     return out
@@ -106,7 +121,7 @@ class BatchEngine:
                 vg.append(default_vgrad(int(st[j]), sp[j], verts))
         mt = mesh_table(spec["meshes"], vg)
         shapes = abi.array_shapes(B, nb, neq, maxc, fric_dirs, max_cand, max_pc, max_sub, len(spec["meshes"]),
-                                  len(mt["verts"]), len(mt["faces"]))
+                                  len(mt["verts"]), len(mt["faces"]), len(mt["fch_box"]), len(mt["vch_box"]))
         kinds = dict(abi.FIELDS)
         self.arr = {}
         for name, shp in shapes.items():

@@ -22,6 +22,7 @@ FIELDS = [
     ("shape_type", "pi"), ("shape_prm", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
     ("mesh_voff", "pi"), ("mesh_nv", "pi"), ("mesh_foff", "pi"), ("mesh_nf", "pi"),
     ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"), ("vgrad", "pd"),
+    ("fch_box", "pd"), ("vch_box", "pd"), ("mesh_fch_off", "pi"), ("mesh_vch_off", "pi"),
     ("Je", "pd"), ("b_eq", "pd"),
     ("t", "pd"), ("t_end", "pd"), ("dt_try", "pd"), ("last_dt", "pd"), ("dt_use", "pd"),
     ("active", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
@@ -30,14 +31,14 @@ FIELDS = [
     ("pose0", "pd"), ("vel0", "pd"),
     ("Mblk", "pd"), ("pvec", "pd"), ("cop", "pd"), ("x", "pd"), ("lam", "pd"), ("slack", "pd"), ("nu", "pd"),
     ("cop_body", "pi"), ("lcp_iters", "pi"), ("lcp_status", "pi"),
-    ("ovl", "pi"), ("invalid", "pi"), ("overflow", "pi"),
+    ("ovl", "pi"), ("pair_list", "pi"), ("n_pairs", "pi"), ("invalid", "pi"), ("overflow", "pi"),
     ("pc_count", "pi"), ("pc_face", "pi"), ("pc_abc", "pd"), ("pc_geom", "pd"),
     ("cand_face", "pi"), ("cand_state", "pi"), ("cand_buf", "pd"),
     ("max_sub", "i"),
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
     ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"),
-    ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"),
+    ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("dbg_stamps", "ev"),
 ]
 
 
@@ -48,7 +49,7 @@ class DssWorld(ctypes.Structure):
 NP_DTYPE = {"pd": np.float64, "pi": np.int32, "pb": np.uint8}
 
 
-def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF):
+def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF, NFC=1, NVC=1):
     """Shapes of every array the kernels touch (state, scratch, tape)."""
     npair = nb * (nb - 1)
     NR = fd + 2
@@ -59,6 +60,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF)
         "fric": (B, nb), "fext": (B, nb, 6), "shape_type": (B, nb), "shape_prm": (B, nb, 3), "mesh_id": (B, nb),
         "no_contact": (nb, nb), "mesh_voff": (nmesh,), "mesh_nv": (nmesh,), "mesh_foff": (nmesh,), "mesh_nf": (nmesh,),
         "verts": (NV, 3), "faces": (NF, 3), "fcent": (NF, 3), "frad": (NF,), "vgrad": (NV, 3),
+        "fch_box": (NFC, 6), "vch_box": (NVC, 6), "mesh_fch_off": (nmesh,), "mesh_vch_off": (nmesh,),
         "Je": (B, max(neq, 1), nz), "b_eq": (B, max(neq, 1)),
         "t": (B,), "t_end": (B,), "dt_try": (B,), "last_dt": (B,), "dt_use": (B,),
         "active": (B,), "toc": (B,), "nsub": (B,), "n_active": (1,),
@@ -67,7 +69,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF)
         "pose0": (B, nb, 7), "vel0": (B, nb, 6),
         "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
         "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
-        "ovl": (B, nb, nb), "invalid": (B,), "overflow": (B,),
+        "ovl": (B, nb, nb), "pair_list": (B * npair,), "n_pairs": (1,), "invalid": (B,), "overflow": (B,),
         "pc_count": (B, npair), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
         "pc_geom": (B, npair, 10, max_pc),
         "cand_face": (B, npair, 2, max_cand), "cand_state": (B, npair, max_cand),

@@ -132,6 +132,10 @@ typedef struct DssWorld {
     const double *fcent;   /* [NF][3] face centroids, */
     const double *frad;    /* [NF]    max centroid-vertex distance (both pose invariant) */
     const double *vgrad;   /* [NV][3] d vertex / d shape parameter: box d v_k/d dims_k ; sphere d v/d rad */
+    /* culling boxes (body frame) of every run of 256 consecutive faces / vertices of a mesh:
+       [NCH][6] = lo(3), hi(3); face boxes bound centroid +- radius.  mesh_fch_off/mesh_vch_off [nmesh]. */
+    const double *fch_box, *vch_box;
+    const int *mesh_fch_off, *mesh_vch_off;
     /* equality rows (joints), constant: Je [B][neq][6 nb], right-hand side b_eq [B][neq] (zeros) */
     const double *Je, *b_eq;
     /* per-scene stepping state [B] */
@@ -157,6 +161,8 @@ typedef struct DssWorld {
     int *cop_body, *lcp_iters, *lcp_status;
     /* narrow phase scratch */
     int *ovl;                /* [B][nb][nb] overlap flags */
+    int *pair_list;          /* [B*npairs] active (scene*npairs + directed pair) work items of this attempt */
+    int *n_pairs;            /* [1] */
     int *invalid;            /* [B] penetration > tol found in this attempt */
     int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
@@ -172,6 +178,8 @@ typedef struct DssWorld {
     int *tp_nc, *tp_body, *tp_face;
     /* optional hipEvent_t pair recorded around the LCP launch of dss_step_attempt (bench roofline) */
     void *ev_lcp_start, *ev_lcp_stop;
+    /* optional [grid of narrowphase][8] phase time stamps (diagnostic runs only; NULL in production) */
+    long long *dbg_stamps;
 } DssWorld;
 
 #define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */

@@ -36,6 +36,7 @@ typedef void *hipStream_t;
 typedef int hipError_t;
 constexpr int hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 typedef void *hipEvent_t;
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 
@@ -168,6 +169,7 @@ inline unsigned long long __ballot(int pred)
     dss_emu::yield();
     return m;
 }
+inline long long wall_clock64() { return 0; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
