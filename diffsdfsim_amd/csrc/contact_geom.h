@@ -17,7 +17,7 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
 {
     Shape<double> sd;
     sd.type = s.type;
-    for (int i = 0; i < 3; ++i) sd.prm[i] = val(s.prm[i]);
+    for (int i = 0; i < 3; ++i) { sd.prm[i] = val(s.prm[i]); sd.hd[i] = val(s.hd[i]); }
     sd.scale = val(s.scale);
     double acc = 0.0, pt[3] = {val(p[0]), val(p[1]), val(p[2])}, g[3];
     for (int i = 0; i < 3; ++i) {

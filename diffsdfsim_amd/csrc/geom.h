@@ -237,21 +237,27 @@ template <class T> struct Shape {
     int type;
     T prm[3];   // box: dims ; sphere: rad
     T scale;    // box: 1.5*max(dims)/2 ; sphere: 1.5*rad   (bodies.py:782, 987)
+    T hd[3];    // box: (dims/scale)/2 ; sphere: hd[0] = rad/scale   (hoisted: invariant per body)
 };
 template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int type, const T *prm)
 {
     s.type = type;
     for (int i = 0; i < 3; ++i) s.prm[i] = prm[i];
-    if (type == SHAPE_BOX) s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
-    else s.scale = prm[0] * 1.5;
+    if (type == SHAPE_BOX) {
+        s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
+        for (int i = 0; i < 3; ++i) s.hd[i] = (prm[i] / s.scale) / 2.0;
+    } else {
+        s.scale = prm[0] * 1.5;
+        s.hd[0] = prm[0] / s.scale; s.hd[1] = T(0.0); s.hd[2] = T(0.0);
+    }
 }
 
 // value and (normalised) gradient of the unit-cube SDF at p = pts/scale, parameters prm/scale
 template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, const T *p, T &phi, T *g, bool want_grad)
 {
     if (s.type == SHAPE_BOX) {
-        T q[3], m[3], hd[3];
-        for (int i = 0; i < 3; ++i) { hd[i] = (s.prm[i] / s.scale) / 2.0; q[i] = t_abs(p[i]) - hd[i]; }
+        T q[3], m[3];
+        for (int i = 0; i < 3; ++i) q[i] = t_abs(p[i]) - s.hd[i];
         const T md = t_max(t_max(q[0], q[1]), q[2]);
         for (int i = 0; i < 3; ++i) m[i] = t_clamp_min(q[i], 0.0);
         phi = norm3(m) + t_clamp_max(md, 0.0);
@@ -271,7 +277,7 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
         }
     } else {
         const T n = norm3(p);
-        phi = n - s.prm[0] / s.scale;
+        phi = n - s.hd[0];
         if (want_grad) { T g1[3]; normalize(p, g1); normalize(g1, g); }
     }
 }

@@ -491,20 +491,53 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         for (int i = 0; i < 3; ++i) { c.x[i] = om * c.x[i] + gm * c.pqr[3 * bi + i]; c.abc[i] *= om; }
         c.abc[bi] += gm;
     };
-    Cand r0;
-    const bool has0 = tid < ncand;
-    if (has0) { load_c(r0, tid); init_c(r0); }
-    for (int k = tid + NT; k < ncand; k += NT) { Cand c; load_c(c, k); init_c(c); store_c(c, k); }
-    __syncthreads();
-    for (int iter = 0; iter < 32; ++iter) {
+    // iteration 0 for everybody; afterwards only candidates that still move are touched: a candidate whose
+    // |improvement| <= tol keeps x, so every later evaluation repeats the same numbers and gamma stays 0
+    // (contacts.py:70-73).  The movers (typically a handful on the rim of a flat contact patch) are packed
+    // to the front so whole wavefronts drop out of the loop.
+    int nmov = 0;
+    {
+        int vote = 0;
+        for (int base = 0; base < ncand; base += NT) {
+            const int k = base + tid;
+            float gm = 0.0f; int bi = 0, pen = 0;
+            if (k < ncand) {
+                Cand c; load_c(c, k); init_c(c);
+                eval_c(c, 0, gm, bi, pen);
+                if (gm != 0.0f && !pen) apply_c(c, gm, bi);   // applied only if the loop is not left (decided below)
+                store_c(c, k);
+                CB(25, k) = (double)gm; cstate[k] = bi;
+            }
+            const unsigned long long bm = __ballot(gm != 0.0f), bp = __ballot(pen);
+            if ((tid & 63) == 0) S.vote[0][tid >> 6] = (bm != 0ull ? 1 : 0) | (bp != 0ull ? 2 : 0);
+            __syncthreads();
+            for (int w = 0; w < NT / 64; ++w) vote |= S.vote[0][w];
+            const int slot = compact_slot(gm != 0.0f, nmov, S);
+            if (slot >= 0 && slot < 1024) S.hidx[slot] = k;
+        }
+        __syncthreads();
+        if (vote & 2) {
+            // a penetrating point in iteration 0: the reference leaves the loop BEFORE the update; undo it
+            for (int k = tid; k < ncand; k += NT) {
+                const float gm = (float)CB(25, k);
+                if (gm != 0.0f) { Cand c; load_c(c, k); init_c(c); store_c(c, k); }
+            }
+            nmov = 0;
+        }
+        if (nmov > 1024) { over |= 2; nmov = 1024; }
+        __syncthreads();
+    }
+    for (int iter = 1; iter < 32 && nmov > 0; ++iter) {
         float gam[MAX_CPT]; int ind[MAX_CPT];
         int any_pen = 0, moving = 0, q = 0, pen;
-        if (has0) { eval_c(r0, iter, gam[0], ind[0], pen); any_pen |= pen; moving |= gam[0] != 0.0f; }
-        q = 1;
-        for (int k = tid + NT; k < ncand; k += NT, ++q) {
+        for (int j = tid; j < nmov; j += NT, ++q) {
+            const int k = S.hidx[j];
+            gam[q] = 0.0f; ind[q] = 0;
+            if (cstate[k] < 0) continue;          // froze earlier
             Cand c; load_c(c, k);
             eval_c(c, iter, gam[q], ind[q], pen);
             any_pen |= pen; moving |= gam[q] != 0.0f;
+            if (gam[q] == 0.0f) cstate[k] = -1;
         }
         const unsigned long long bm = __ballot(moving), bp = __ballot(any_pen);
         if ((tid & 63) == 0) S.vote[iter & 1][tid >> 6] = (bm != 0ull ? 1 : 0) | (bp != 0ull ? 2 : 0);
@@ -512,11 +545,13 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         int vote = 0;
         for (int w = 0; w < NT / 64; ++w) vote |= S.vote[iter & 1][w];
         if (!(vote & 1) || (vote & 2)) break;   // all gamma == 0, or a penetrating point (contacts.py:74-77)
-        if (has0) apply_c(r0, gam[0], ind[0]);
-        q = 1;
-        for (int k = tid + NT; k < ncand; k += NT, ++q) { Cand c; load_c(c, k); apply_c(c, gam[q], ind[q]); store_c(c, k); }
+        q = 0;
+        for (int j = tid; j < nmov; j += NT, ++q) {
+            if (gam[q] == 0.0f) continue;
+            const int k = S.hidx[j];
+            Cand c; load_c(c, k); apply_c(c, gam[q], ind[q]); store_c(c, k);
+        }
     }
-    if (has0) store_c(r0, tid);
     __syncthreads();
 
     STAMP(2);
