@@ -29,6 +29,15 @@
 #include "../../include/diffsdfsim_hip.h"
 #include "wave_utils.h"
 
+#if defined(DSS_DIAG)   // diagnostic build only (tools_lcp_phases.py); the product library has no global state
+__device__ long long *g_lcp_stamps = nullptr;
+#define LSTAMP(i) do { if (g_lcp_stamps && threadIdx.x == 0) atomicAdd((unsigned long long *)&g_lcp_stamps[(size_t)blockIdx.x * 16 + (i)], (unsigned long long)(wall_clock64() - t_last)); t_last = wall_clock64(); } while (0)
+#define LSTAMP_INIT long long t_last = wall_clock64()
+#else
+#define LSTAMP(i) do { } while (0)
+#define LSTAMP_INIT do { } while (0)
+#endif
+
 namespace {
 using namespace dss;
 
@@ -485,6 +494,8 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 
     double best = 0.0;
     int have_best = 0, not_improved = 0, it = 0;
+    LSTAMP_INIT;
+    LSTAMP(0);
     for (it = 0; it < max_iter; ++it) {
         // ---- residuals (batch.py:117-131) and the affine right-hand side ---------------------
         double acc_rz = 0.0, acc_sz = 0.0;
@@ -517,7 +528,9 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         acc_rz = wave_sum(acc_rz);
         const double sz = wave_sum(acc_sz);
         __syncthreads();
+        LSTAMP(1);
         gather<2>(L, L.g1, L.g2);  // g1 = G^T z, g2 = G^T W (rz - s)
+        LSTAMP(2);
         double rx = 0.0, ry = 0.0;
         if (lane < nz) {
             rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane];
@@ -544,6 +557,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             ++not_improved;
         }
         if (not_improved == not_improved_lim || best < eps || mu > 1e32) break;
+        LSTAMP(3);
 
         // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
         __syncthreads();
@@ -558,8 +572,11 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
         }
         __syncthreads();
+        LSTAMP(4);
         assemble_K(L, Mblk, A, cbody, nc);
+        LSTAMP(5);
         factor_K(L);
+        LSTAMP(6);
         {
             double rhs = 0.0;
             if (lane < nz) rhs = -rx - L.g2[lane];
@@ -568,6 +585,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             if (lane < n) L.dxa[lane] = sol;
         }
         __syncthreads();
+        LSTAMP(7);
         StepAcc stz, sts;
         for (int c = lane; c < nc; c += WAVE) {
             Geo<ND> g;
@@ -593,6 +611,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         }
         double alpha = fmin(fmin(stz.finish(), sts.finish()), 1.0);
         __syncthreads();
+        LSTAMP(8);
         double t3 = 0.0;
         for (int c = lane; c < nc; c += WAVE)
 #pragma unroll
@@ -620,6 +639,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = w[j];
         }
         __syncthreads();
+        LSTAMP(9);
         gather<1>(L, L.g1, nullptr);
         {
             double rhs = (lane < nz) ? L.g1[lane] : 0.0;
@@ -627,6 +647,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             if (lane < n) L.sol[lane] = sol;
         }
         __syncthreads();
+        LSTAMP(10);
         StepAcc stz2, sts2;
         for (int c = lane; c < nc; c += WAVE) {
             Geo<ND> g;
@@ -654,6 +675,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         }
         alpha = fmin(0.999 * fmin(stz2.finish(), sts2.finish()), 1.0);
         __syncthreads();
+        LSTAMP(11);
         if (lane < n) L.xv[lane] += alpha * (L.dxa[lane] + L.sol[lane]);
         for (int c = lane; c < nc; c += WAVE)
 #pragma unroll
@@ -662,6 +684,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
                 cz[(size_t)q * maxc + c] += alpha * cdz[(size_t)q * maxc + c];
             }
         __syncthreads();
+        LSTAMP(12);
     }
     if (lane == 0) { iters[sc] = it; status[sc] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
 }
@@ -782,6 +805,14 @@ inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
 }
 
 }  // namespace
+
+#if defined(DSS_DIAG)
+__global__ void set_lcp_stamps_kernel(long long *p) { g_lcp_stamps = p; }
+extern "C" void dss_diag_set_lcp_stamps(long long *p, void *stream)
+{
+    hipLaunchKernelGGL(set_lcp_stamps_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+}
+#endif
 
 extern "C" {
 
