@@ -27,6 +27,7 @@
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"
+#include "kkt_reg.h"
 #include "wave_utils.h"
 
 #if defined(DSS_DIAG)   // diagnostic build only (tools_lcp_phases.py); the product library has no global state
@@ -356,6 +357,40 @@ __device__ double solve_K(const Lds &L, double x)
     return x;
 }
 
+
+// K factor + solves: register-resident for the compiled sizes (n = 54: 8 bodies + 6 equality rows, the
+// configuration BASELINE.json is quoted on; n = 18: 2 bodies), LDS fallback for any other n <= 64.
+template <int N> __device__ double kkt_factor_solve_reg(Lds &L, double rhs)
+{
+    RegK<N> R;
+    regk_load<N>(R, L.K, L.lda);
+    regk_factor<N>(R);
+    const double x = regk_solve<N>(R, rhs);
+    __syncthreads();
+    regk_store<N>(R, L.K, L.lda, L.piv);
+    __syncthreads();
+    return x;
+}
+template <int N> __device__ double kkt_solve_reg(Lds &L, double rhs)
+{
+    RegK<N> R;
+    regk_reload<N>(R, L.K, L.lda, L.piv);
+    return regk_solve<N>(R, rhs);
+}
+__device__ double kkt_factor_solve(Lds &L, double rhs)
+{
+    if (L.n == 54) return kkt_factor_solve_reg<54>(L, rhs);
+    if (L.n == 18) return kkt_factor_solve_reg<18>(L, rhs);
+    factor_K(L);
+    return solve_K(L, rhs);
+}
+__device__ double kkt_solve(Lds &L, double rhs)
+{
+    if (L.n == 54) return kkt_solve_reg<54>(L, rhs);
+    if (L.n == 18) return kkt_solve_reg<18>(L, rhs);
+    return solve_K(L, rhs);
+}
+
 // (Q v)_i for the block-diagonal Q
 __device__ inline double q_times(const double *Mblk, const double *v, int i)
 {
@@ -440,7 +475,6 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
     }
     __syncthreads();
     assemble_K(L, Mblk, A, cbody, nc);
-    factor_K(L);
     for (int c = lane; c < nc; c += WAVE)
 #pragma unroll
         for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = cds[(size_t)j * maxc + c];
@@ -450,7 +484,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         double rhs = 0.0;
         if (lane < nz) rhs = -L.pl[lane] - L.g1[lane];
         else if (lane < n) rhs = bvec[lane - nz];
-        const double sol = solve_K(L, rhs);
+        const double sol = kkt_factor_solve(L, rhs);
         if (lane < n) L.xv[lane] = sol;
     }
     __syncthreads();
@@ -575,13 +609,12 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         LSTAMP(4);
         assemble_K(L, Mblk, A, cbody, nc);
         LSTAMP(5);
-        factor_K(L);
         LSTAMP(6);
         {
             double rhs = 0.0;
             if (lane < nz) rhs = -rx - L.g2[lane];
             else if (lane < n) rhs = -ry;
-            const double sol = solve_K(L, rhs);
+            const double sol = kkt_factor_solve(L, rhs);
             if (lane < n) L.dxa[lane] = sol;
         }
         __syncthreads();
@@ -643,7 +676,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         gather<1>(L, L.g1, nullptr);
         {
             double rhs = (lane < nz) ? L.g1[lane] : 0.0;
-            const double sol = solve_K(L, rhs);
+            const double sol = kkt_solve(L, rhs);
             if (lane < n) L.sol[lane] = sol;
         }
         __syncthreads();
@@ -737,10 +770,9 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
     }
     __syncthreads();
     assemble_K(L, Mblk, A, cbody, nc);
-    factor_K(L);
     {
         const double rhs = (lane < nz) ? -dl_dx_[(size_t)sc * nz + lane] : 0.0;
-        const double sol = solve_K(L, rhs);
+        const double sol = kkt_factor_solve(L, rhs);
         if (lane < n) L.sol[lane] = sol;
     }
     __syncthreads();

@@ -170,6 +170,8 @@ inline unsigned long long __ballot(int pred)
     return m;
 }
 inline long long wall_clock64() { return 0; }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
