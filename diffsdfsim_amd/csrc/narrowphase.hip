@@ -353,8 +353,13 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                 __syncthreads();
             }
             const int nxt = S.red_i[0];
-            __syncthreads();
-            if (nxt < 0 || nxt == iS) break;
+            const int seen = nxt >= 0 ? S.hflag[nxt] : 0;
+            __syncthreads();   // every thread has read red_i / hflag before thread 0 flags the next vertex
+            if (nxt < 0 || nxt == iS || seen) break;
+            {   // coincident with the start (shared mesh vertices produce exact duplicates): the loop is closed
+                const double dx = S.hp[3 * nxt + c0] - S.hp[3 * iS + c0], dy = S.hp[3 * nxt + c1] - S.hp[3 * iS + c1];
+                if (!(dx * dx + dy * dy > tolf * tolf)) break;
+            }
             cur = nxt;
         }
         __syncthreads();
