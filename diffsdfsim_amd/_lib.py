@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH] + srcs
+    extra = os.environ.get("DSS_HIPCC_FLAGS", "").split()
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"] + extra + ["-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

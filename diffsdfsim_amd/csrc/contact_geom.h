@@ -60,6 +60,57 @@ __host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const Body
     pen = -d2;
 }
 
+// ---- time-of-contact distance function (World.H.D, lcp_physics/physics/world.py:150-174) composed with the
+// preprocessing of its arguments at world.py:276-319.  Input order (43): h, hc (the dt_ used to rewind the poses),
+// p1(3) p2(3) n(3) of the new contact, V1(6) V2(6) new velocities, q1(4) x1(3) q2(4) x2(3) poses after the move,
+// a1(3) a2(3) linear accelerations f/m.
+template <class T> __host__ __device__ inline T toc_D(const T *in)
+{
+    const T h = in[0], hc = in[1];
+    const T *p1 = in + 2, *p2 = in + 5, *n = in + 8, *V1 = in + 11, *V2 = in + 17, *q1 = in + 23, *x1 = in + 27,
+            *q2 = in + 30, *x2 = in + 34, *a1 = in + 37, *a2 = in + 40;
+    T R1[9], R2[9], r1[9], r2[9], R10[9], R20[9], w[3], pos1[3], pos2[3];
+    for (int i = 0; i < 3; ++i) { pos1[i] = x1[i] - hc * V1[3 + i]; pos2[i] = x2[i] - hc * V2[3 + i]; }
+    for (int i = 0; i < 3; ++i) w[i] = -hc * V1[i];
+    so3_exp(w, r1);
+    for (int i = 0; i < 3; ++i) w[i] = -hc * V2[i];
+    so3_exp(w, r2);
+    quat_to_mat(q1, R1);
+    quat_to_mat(q2, R2);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            R10[3 * a + b] = r1[3 * a] * R1[b] + r1[3 * a + 1] * R1[3 + b] + r1[3 * a + 2] * R1[6 + b];
+            R20[3 * a + b] = r2[3 * a] * R2[b] + r2[3 * a + 1] * R2[3 + b] + r2[3 * a + 2] * R2[6 + b];
+        }
+    T cs1[3], cs2[3], ns2[3];
+    for (int i = 0; i < 3; ++i) {   // R0^T v
+        cs1[i] = R10[i] * p1[0] + R10[3 + i] * p1[1] + R10[6 + i] * p1[2];
+        cs2[i] = R20[i] * p2[0] + R20[3 + i] * p2[1] + R20[6 + i] * p2[2];
+        ns2[i] = R20[i] * n[0] + R20[3 + i] * n[1] + R20[6 + i] * n[2];
+    }
+    T dRi[9], dRj[9], Rih[9], Rjh[9];
+    for (int i = 0; i < 3; ++i) w[i] = h * V1[i];
+    so3_exp(w, dRi);
+    for (int i = 0; i < 3; ++i) w[i] = h * V2[i];
+    so3_exp(w, dRj);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            Rih[3 * a + b] = dRi[3 * a] * R10[b] + dRi[3 * a + 1] * R10[3 + b] + dRi[3 * a + 2] * R10[6 + b];
+            Rjh[3 * a + b] = dRj[3 * a] * R20[b] + dRj[3 * a + 1] * R20[3 + b] + dRj[3 * a + 2] * R20[6 + b];
+        }
+    T ciw[3], rel[3], D = T(0.0);
+    for (int i = 0; i < 3; ++i) {
+        const T pih = pos1[i] + h * V1[3 + i] + 0.5 * a1[i] * h * h, pjh = pos2[i] + h * V2[3 + i] + 0.5 * a2[i] * h * h;
+        ciw[i] = Rih[3 * i] * cs1[0] + Rih[3 * i + 1] * cs1[1] + Rih[3 * i + 2] * cs1[2] + pih;
+        rel[i] = ciw[i] - pjh;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const T cij = Rjh[i] * rel[0] + Rjh[3 + i] * rel[1] + Rjh[6 + i] * rel[2];   // Rjh^T rel
+        D = D + ns2[i] * (cs2[i] - cij);
+    }
+    return D;
+}
+
 // friction directions of World3D.Jf (physics3d/world.py:84-94; utils.py:247-256 `orthogonal`)
 template <class T> __host__ __device__ inline void friction_dirs(const T *n, int nd, T D[][3])
 {

@@ -18,6 +18,7 @@
 // points are flat).  Here: flatness tests with the same fall-back order, a gift-wrapping hull in
 // 2-D (collinear points dropped), min/max in 1-D and a supporting-plane test in 3-D.
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/diffsdfsim_hip.h"
 #include "contact_geom.h"
@@ -703,13 +704,22 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
 #undef CB
 }
 
-// persistent: every workgroup walks the active-pair list with a grid stride
-__global__ void __launch_bounds__(NT) narrowphase_kernel(DssWorld W)
+// persistent: workgroups pull items off the active-pair list through a shared cursor (n_pairs[1]) so that the
+// long items (a 176 k-face floor against a box) do not leave a static-partition tail
+#ifndef DSS_NP_WAVES
+#define DSS_NP_WAVES 3   // waves per SIMD the register allocator must leave room for (= workgroups per CU)
+#endif
+__global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W)
 {
     __shared__ Scratch S;
+    __shared__ int s_item;
     const int n = W.n_pairs[0];
-    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    for (;;) {
         __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(W.n_pairs + 1, 1);
+        __syncthreads();
+        const int it = s_item;
+        if (it >= n) break;
         narrow_pair(W, S, W.pair_list[it]);
     }
 }
@@ -755,10 +765,11 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
 {
     if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
-    hipMemsetAsync(W.n_pairs, 0, sizeof(int), stream);
+    hipMemsetAsync(W.n_pairs, 0, 2 * sizeof(int), stream);   // [0] list length, [1] work cursor
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
     // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
-    const int grid = W.B * np < 256 * 3 ? W.B * np : 256 * 3;
+    static const int wgs_per_cu = getenv("DSS_NP_WGS_PER_CU") ? atoi(getenv("DSS_NP_WGS_PER_CU")) : DSS_NP_WAVES;
+    const int grid = W.B * np < 256 * wgs_per_cu ? W.B * np : 256 * wgs_per_cu;
     hipLaunchKernelGGL(narrowphase_kernel, dim3(grid), dim3(NT), 0, stream, W);
     hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;

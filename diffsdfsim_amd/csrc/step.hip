@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
                     W.tp_slack[(rec * NR + q) * MX + c] = W.slack[((size_t)sc * NR + q) * MX + c];
                 }
             }
-            if (lane == 0) { W.tp_dt[rec] = W.dt_use[sc]; W.tp_nc[rec] = nc_old; }
+            if (lane == 0) {
+                W.tp_dt[rec] = W.dt_use[sc]; W.tp_nc[rec] = nc_old;
+                W.tp_flags[rec] = ((W.toc_diff && toc) ? 1 : 0) | ((W.toc_diff && W.toc[sc]) ? 2 : 0);
+            }
         }
         __syncthreads();
         // commit the new contacts

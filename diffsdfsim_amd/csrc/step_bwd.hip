@@ -121,6 +121,97 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         view_slot(W, sc, k, v);
     }
 
+    // (0) time-of-contact event (world.py:272-341): dt_h = H(dt_, theta).  Its adjoint is that of the redone
+    //     move plus the carry from the next sub-step (whose dt_ = -last_dt + ...); H.backward (world.py:195-237)
+    //     turns it into adjoints of the new contacts' geometry, the new velocities, the moved poses and f/m.
+    const int flags = init ? 0 : W.tp_flags[(size_t)k * W.B + sc];
+    const int ev = flags & 1;
+    double dt_int = 0.0;   // d(loss)/d(dt) through the pose integration, seed = pose adjoint before the TOC terms
+    if (!init) {
+        double part = 0.0;
+        if (lane < nb) {
+            typedef Dual<1> D;
+            D ps[7], vv[6], out[7], dt(v.dt);
+            dt.d[0] = 1.0;
+            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
+            for (int i = 0; i < 6; ++i) vv[i] = D(-v.x[6 * lane + i]);
+            integrate_pose(ps, vv, dt, out);
+            for (int o = 0; o < 7; ++o) part += a_pose[7 * lane + o] * out[o].d[0];
+        }
+        dt_int = wave_sum(part);
+    }
+    double hc_bar = 0.0;
+    if (ev) {
+        const double dtbar_h = dt_int + A.a_last_dt[sc];
+        const double h = v.dt;
+        double dDdh[3] = {0, 0, 0};   // up to 3 contacts per lane (maxc <= 192)
+        int q = 0;
+        double den = 0.0;
+        auto fill = [&](int c, double *in) {
+            const int b1 = v.body_n[c], b2 = v.body_n[MX + c];
+            in[0] = h; in[1] = h;
+            const double *gn = (k + 1 < W.nsub[sc]) ? W.tp_geom + ((size_t)(k + 1) * W.B + sc) * 10 * MX : W.c_geom + (size_t)sc * 10 * MX;
+            for (int i = 0; i < 3; ++i) { in[2 + i] = gn[(size_t)(3 + i) * MX + c]; in[5 + i] = gn[(size_t)(6 + i) * MX + c]; in[8 + i] = gn[(size_t)i * MX + c]; }
+            for (int i = 0; i < 6; ++i) { in[11 + i] = -v.x[6 * b1 + i]; in[17 + i] = -v.x[6 * b2 + i]; }
+            for (int i = 0; i < 7; ++i) { in[23 + i] = v.pose_n[7 * b1 + i]; in[30 + i] = v.pose_n[7 * b2 + i]; }
+            for (int i = 0; i < 3; ++i) {
+                in[37 + i] = W.fext[((size_t)sc * nb + b1) * 6 + 3 + i] / W.mass[(size_t)sc * nb + b1];
+                in[40 + i] = W.fext[((size_t)sc * nb + b2) * 6 + 3 + i] / W.mass[(size_t)sc * nb + b2];
+            }
+        };
+        auto is_toc = [&](int c) {
+            const int a = v.body_n[c], b = v.body_n[MX + c];
+            for (int j = 0; j < v.nc_k; ++j) {
+                const int a0 = v.body_k[j], b0 = v.body_k[MX + j];
+                if ((a0 == a && b0 == b) || (a0 == b && b0 == a)) return false;
+            }
+            return true;
+        };
+        for (int c = lane; c < v.nc_n; c += 64, ++q) {
+            if (!is_toc(c)) continue;
+            double in[43];
+            fill(c, in);
+            typedef Dual<1> D;
+            D di[43];
+            for (int i = 0; i < 43; ++i) di[i] = D(in[i]);
+            di[0].d[0] = 1.0;
+            double g = toc_D(di).d[0];
+            if (g < 1e-6 / h) g = 0.0;          // only motion into collision (world.py:203; Defaults.TOL = 1e-6)
+            if (q < 3) dDdh[q] = g;
+            den += g * g;
+        }
+        den = wave_sum(den);
+        q = 0;
+        for (int c = lane; c < v.nc_n; c += 64, ++q) {
+            for (int r = 20; r < 53; ++r) cs[(size_t)r * MX + c] = 0.0;
+            if (!(den > 1e-5) || q >= 3 || dDdh[q] == 0.0) continue;
+            const double wgt = -(dDdh[q] / den) * dtbar_h;
+            double in[43], outg[44];
+            fill(c, in);
+            for (int grp = 0; grp < 11; ++grp) {
+                typedef Dual<4> D;
+                D di[43];
+                for (int i = 0; i < 43; ++i) { di[i] = D(in[i]); const int sl = i - 4 * grp; if (sl >= 0 && sl < 4) di[i].d[sl] = 1.0; }
+                const D r = toc_D(di);
+                for (int sl = 0; sl < 4; ++sl) outg[4 * grp + sl] = wgt * r.d[sl];
+            }
+            // geometry of the new contact
+            for (int i = 0; i < 3; ++i) {
+                a_geom[(size_t)(3 + i) * MX + c] += outg[2 + i];
+                a_geom[(size_t)(6 + i) * MX + c] += outg[5 + i];
+                a_geom[(size_t)i * MX + c] += outg[8 + i];
+            }
+            for (int i = 0; i < 7; ++i) { cs[(size_t)(20 + i) * MX + c] = outg[23 + i]; cs[(size_t)(27 + i) * MX + c] = outg[30 + i]; }
+            for (int i = 0; i < 6; ++i) { cs[(size_t)(34 + i) * MX + c] = outg[11 + i]; cs[(size_t)(40 + i) * MX + c] = outg[17 + i]; }
+            for (int i = 0; i < 3; ++i) { cs[(size_t)(46 + i) * MX + c] = outg[37 + i]; cs[(size_t)(49 + i) * MX + c] = outg[40 + i]; }
+            cs[(size_t)52 * MX + c] = outg[1];
+        }
+        __syncthreads();
+        double hp = 0.0;
+        for (int c = lane; c < v.nc_n; c += 64) hp += cs[(size_t)52 * MX + c];
+        hc_bar = wave_sum(hp);
+    }
+
     // (a) contacts detected after the sub-step: geometry adjoint -> pose after the sub-step, shape params
     for (int c = lane; c < v.nc_n; c += 64) {
         double gb[9], out[20];
@@ -144,6 +235,28 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
             }
         }
         for (int i = 0; i < 3; ++i) A.g_prm[((size_t)sc * nb + lane) * 3 + i] += gp[i];
+        if (ev) {   // pieces of H.backward that land on this body: moved pose, new velocity, f/m
+            double vx[6] = {0, 0, 0, 0, 0, 0}, ab[3] = {0, 0, 0};
+            for (int c = 0; c < v.nc_n; ++c) {
+                if (v.body_n[c] == lane) {
+                    for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)(20 + i) * MX + c];
+                    for (int i = 0; i < 6; ++i) vx[i] += cs[(size_t)(34 + i) * MX + c];
+                    for (int i = 0; i < 3; ++i) ab[i] += cs[(size_t)(46 + i) * MX + c];
+                }
+                if (v.body_n[MX + c] == lane) {
+                    for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)(27 + i) * MX + c];
+                    for (int i = 0; i < 6; ++i) vx[i] += cs[(size_t)(40 + i) * MX + c];
+                    for (int i = 0; i < 3; ++i) ab[i] += cs[(size_t)(49 + i) * MX + c];
+                }
+            }
+            const size_t bi = (size_t)sc * nb + lane;
+            const double m = W.mass[bi];
+            for (int i = 0; i < 3; ++i) {   // a = f/m
+                A.g_fext[bi * 6 + 3 + i] += ab[i] / m;
+                A.g_mass[bi] -= ab[i] * W.fext[bi * 6 + 3 + i] / (m * m);
+            }
+            for (int i = 0; i < 6; ++i) a_vel[6 * lane + i] += vx[i];   // joins the adjoint of the new velocity
+        }
         for (int i = 0; i < 7; ++i) a_pose[7 * lane + i] = ap[i];
     }
     if (init) {
@@ -174,6 +287,17 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
             integrate_pose(ps, vv, dt, out);
             for (int s = 0; s < 6; ++s) { double acc = 0.0; for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[s]; avn[s] = acc; }
         }
+        {   // d/d(dt) of the integration with the complete pose adjoint (first move and redone move share it)
+            typedef Dual<1> D;
+            D ps[7], vv[6], out[7], dt(v.dt);
+            dt.d[0] = 1.0;
+            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
+            for (int i = 0; i < 6; ++i) vv[i] = D(vnew[i]);
+            integrate_pose(ps, vv, dt, out);
+            double acc = 0.0;
+            for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[0];
+            cs[(size_t)53 * MX + lane] = acc;
+        }
         for (int i = 0; i < 7; ++i) a_pose[7 * lane + i] = apk[i];
         // total adjoint of v_new = (later uses, already in a_vel) + (integration); x = -v_new
         for (int i = 0; i < 6; ++i) A.a_x[(size_t)sc * 6 * nb + 6 * lane + i] = -(a_vel[6 * lane + i] + avn[i]);
@@ -186,6 +310,12 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         for (int r = 0; r < 6; ++r)
             for (int c = 0; c < 6; ++c) M[6 * r + c] = (r < 3 && c < 3) ? Iw[3 * r + c] : ((r == c) ? m : 0.0);
         for (int i = 0; i < 6; ++i) W.x[(size_t)sc * 6 * nb + 6 * lane + i] = v.x[6 * lane + i];
+    }
+    __syncthreads();
+    {
+        double part = (lane < nb) ? cs[(size_t)53 * MX + lane] : 0.0;
+        part = wave_sum(part);
+        if (lane == 0) A.a_dt[sc] = part + hc_bar + (ev ? A.a_last_dt[sc] : 0.0);
     }
     if (lane < W.neq) W.nu[(size_t)sc * W.neq + lane] = v.nu[lane];
     const int ND = W.fric_dirs / 2, NF = 3 * (1 + ND) + 8, NR = W.fric_dirs + 2;
@@ -317,7 +447,16 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
             for (int s = 0; s < 4; ++s) { double acc = 0.0; for (int e = 0; e < 9; ++e) acc += Iwbar[e] * out[e].d[s]; a_pose[7 * lane + s] += acc; }
         }
     }
-    if (lane == 0) A.cur_slot[sc] = k - 1;
+    {   // u = M v + dt f : d/d(dt) = ubar . f ;  a sub-step whose dt_ was formed with last_dt hands -dt_bar back
+        double part = 0.0;
+        if (lane < nb) for (int i = 0; i < 6; ++i) part += du[6 * lane + i] * W.fext[((size_t)sc * nb + lane) * 6 + i];
+        part = wave_sum(part);
+        if (lane == 0) {
+            const double dtbar = A.a_dt[sc] + part;
+            A.a_last_dt[sc] = (W.tp_flags[(size_t)k * W.B + sc] & 2) ? -dtbar : 0.0;
+            A.cur_slot[sc] = k - 1;
+        }
+    }
 }
 
 }  // namespace

@@ -41,6 +41,7 @@ class _StepFn(torch.autograd.Function):
         adj = E._adjoint()
         if ctx.index == w._n_nodes - 1 or w._bw_next != ctx.index:   # newest node: start a fresh reverse sweep
             adj["a_geom"].zero_()
+            adj["a_last_dt"].zero_()
             adj["cur_slot"].copy_(E.arr["nsub"] - 1)
         w._bw_next = ctx.index - 1
         for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm"):

@@ -37,7 +37,7 @@ FIELDS = [
     ("max_sub", "i"),
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
-    ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"),
+    ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"), ("tp_flags", "pi"),
     ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("dbg_stamps", "ev"),
 ]
 
@@ -69,7 +69,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
         "pose0": (B, nb, 7), "vel0": (B, nb, 6),
         "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
         "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
-        "ovl": (B, nb, nb), "pair_list": (B * npair,), "n_pairs": (1,), "invalid": (B,), "overflow": (B,),
+        "ovl": (B, nb, nb), "pair_list": (B * npair,), "n_pairs": (2,), "invalid": (B,), "overflow": (B,),
         "pc_count": (B, npair), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
         "pc_geom": (B, npair, 10, max_pc),
         "cand_face": (B, npair, 2, max_cand), "cand_state": (B, npair, max_cand),
@@ -80,13 +80,13 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
             "tp_pose": (max_sub, B, nb, 7), "tp_vel": (max_sub, B, nb, 6), "tp_dt": (max_sub, B), "tp_x": (max_sub, B, nz),
             "tp_lam": (max_sub, B, NR, maxc), "tp_slack": (max_sub, B, NR, maxc), "tp_nu": (max_sub, B, max(neq, 1)),
             "tp_abc": (max_sub, B, 3, maxc), "tp_geom": (max_sub, B, 10, maxc),
-            "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc),
+            "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc), "tp_flags": (max_sub, B),
         })
     return s
 
 
 ADJ_FIELDS = [
-    ("a_pose", "pd"), ("a_vel", "pd"), ("a_geom", "pd"),
+    ("a_pose", "pd"), ("a_vel", "pd"), ("a_geom", "pd"), ("a_last_dt", "pd"), ("a_dt", "pd"),
     ("g_mass", "pd"), ("g_inertia", "pd"), ("g_rest", "pd"), ("g_fric", "pd"), ("g_fext", "pd"), ("g_prm", "pd"),
     ("cur_slot", "pi"), ("lo_slot", "pi"), ("bw_active", "pi"),
     ("a_x", "pd"), ("dMblk", "pd"), ("dpvec", "pd"), ("dcop", "pd"), ("cscr", "pd"), ("bw_nc", "pi"),
@@ -100,9 +100,9 @@ class DssAdjoint(ctypes.Structure):
 def adjoint_shapes(B, nb, maxc, fd):
     NFc = 3 * (1 + fd // 2) + 8
     return {
-        "a_pose": (B, nb, 7), "a_vel": (B, nb, 6), "a_geom": (B, 10, maxc),
+        "a_pose": (B, nb, 7), "a_vel": (B, nb, 6), "a_geom": (B, 10, maxc), "a_last_dt": (B,), "a_dt": (B,),
         "g_mass": (B, nb), "g_inertia": (B, nb, 9), "g_rest": (B, nb), "g_fric": (B, nb), "g_fext": (B, nb, 6),
         "g_prm": (B, nb, 3), "cur_slot": (B,), "lo_slot": (B,), "bw_active": (B,),
         "a_x": (B, 6 * nb), "dMblk": (B, nb, 36), "dpvec": (B, 6 * nb), "dcop": (B, NFc, maxc),
-        "cscr": (B, 20, maxc), "bw_nc": (B,),
+        "cscr": (B, 56, maxc), "bw_nc": (B,),
     }

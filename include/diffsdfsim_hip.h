@@ -162,7 +162,7 @@ typedef struct DssWorld {
     /* narrow phase scratch */
     int *ovl;                /* [B][nb][nb] overlap flags */
     int *pair_list;          /* [B*npairs] active (scene*npairs + directed pair) work items of this attempt */
-    int *n_pairs;            /* [1] */
+    int *n_pairs;            /* [2]: list length, work cursor of the persistent narrow phase */
     int *invalid;            /* [B] penetration > tol found in this attempt */
     int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
@@ -176,6 +176,7 @@ typedef struct DssWorld {
     int max_sub;
     double *tp_pose, *tp_vel, *tp_dt, *tp_x, *tp_lam, *tp_slack, *tp_nu, *tp_abc, *tp_geom;
     int *tp_nc, *tp_body, *tp_face;
+    int *tp_flags;   /* bit 0: the sub-step ended with a time-of-contact event, bit 1: its dt_ used last_dt (world.py:253-257) */
     /* optional hipEvent_t pair recorded around the LCP launch of dss_step_attempt (bench roofline) */
     void *ev_lcp_start, *ev_lcp_stop;
     /* optional [grid of narrowphase][8] phase time stamps (diagnostic runs only; NULL in production) */
@@ -183,6 +184,7 @@ typedef struct DssWorld {
 } DssWorld;
 
 #define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */
+#define DSS_CSCR_ROWS 56
 #define DSS_SHAPE_BOX 0
 #define DSS_SHAPE_SPHERE 1
 
@@ -211,13 +213,15 @@ int dss_find_contacts(const DssWorld *W, void *stream);
  * ------------------------------------------------------------------------------------ */
 typedef struct DssAdjoint {
     double *a_pose, *a_vel, *a_geom;
+    double *a_last_dt;       /* [B] adjoint of World.last_dt carried to the sub-step that produced it */
+    double *a_dt;            /* [B] scratch: adjoint of dt_ of the sub-step being processed */
     double *g_mass, *g_inertia, *g_rest, *g_fric, *g_fext, *g_prm;
     int *cur_slot, *lo_slot;
     /* scratch */
     int *bw_active;          /* [B] */
     double *a_x;             /* [B][6 nb] */
     double *dMblk, *dpvec, *dcop;   /* LCP backward outputs, shapes of Mblk / pvec / cop */
-    double *cscr;            /* [B][20][maxc] per-contact VJP pieces */
+    double *cscr;            /* [B][DSS_CSCR_ROWS][maxc] per-contact VJP pieces */
     int *bw_nc;              /* [B] */
 } DssAdjoint;
 

@@ -19,11 +19,13 @@ def build_sphere_world(g, toc):
     return w, floor, ball, rad
 
 
-def test_world3d_rollout_and_gradient_match_reference():
-    """Same scene as tests/golden/rollout_sphere_notoc.npz built through the public API; the floor mesh comes from
-    diffsdfsim_amd.meshes (1 ulp from the reference's torch.linspace), so trajectories agree to ~1e-9, not 1e-12."""
-    g = R.load_rollout("rollout_sphere_notoc")
-    w, floor, ball, rad = build_sphere_world(g, toc=False)
+@pytest.mark.parametrize("name,toc", [("rollout_sphere_notoc", False), ("rollout_sphere", True)])
+def test_world3d_rollout_and_gradient_match_reference(name, toc):
+    """Same scene as the golden built through the public API (with and without the time-of-contact differential,
+    World.H); the floor mesh comes from diffsdfsim_amd.meshes (1 ulp from the reference's torch.linspace), so
+    trajectories agree to ~1e-9, not 1e-12."""
+    g = R.load_rollout(name)
+    w, floor, ball, rad = build_sphere_world(g, toc=toc)
     for _ in range(24):
         w.step(fixed_dt=True)
     k = len(g["traj_t"]) - 1
