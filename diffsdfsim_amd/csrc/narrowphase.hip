@@ -141,8 +141,11 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
 }
 
 // ---- workgroup scratch ------------------------------------------------------------------------
+constexpr int MAX_CH = 704;     // runs of 256 faces handled by the barrier-free scan (176 k-face floor = 688)
+
 struct Scratch {
     int wave_tot[NT / 64];
+    int woff[MAX_CH * 4];
     int vote[2][NT / 64];
     int red_i[NT];
     double red_d[NT];
@@ -255,10 +258,24 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
         if (!(ln / lab > tolf)) { line = true; flat3 = true; }
         else {
             for (int d = 0; d < 3; ++d) nrm[d] /= ln;
-            double mx = 0.0;
-            for (int k = tid; k < m; k += NT)
-                mx = fmax(mx, fabs(nrm[0] * (S.hp[3 * k] - A[0]) + nrm[1] * (S.hp[3 * k + 1] - A[1]) + nrm[2] * (S.hp[3 * k + 2] - A[2])));
-            if (!(block_max(mx, S) > tolf)) flat3 = true;
+            double mx = -INFINITY, mn = INFINITY; int imx = -1, imn = -1;
+            for (int k = tid; k < m; k += NT) {
+                const double sd = nrm[0] * (S.hp[3 * k] - A[0]) + nrm[1] * (S.hp[3 * k + 1] - A[1]) + nrm[2] * (S.hp[3 * k + 2] - A[2]);
+                if (sd > mx) { mx = sd; imx = k; }
+                if (sd < mn) { mn = sd; imn = k; }
+            }
+            const int gmx = block_argmin(-mx, imx, S), gmn = block_argmin(mn, imn, S);
+            const double dmx = nrm[0] * (S.hp[3 * gmx] - A[0]) + nrm[1] * (S.hp[3 * gmx + 1] - A[1]) + nrm[2] * (S.hp[3 * gmx + 2] - A[2]);
+            const double dmn = nrm[0] * (S.hp[3 * gmn] - A[0]) + nrm[1] * (S.hp[3 * gmn + 1] - A[1]) + nrm[2] * (S.hp[3 * gmn + 2] - A[2]);
+            const double thick = fmax(fabs(dmx), fabs(dmn));
+            if (!(thick > tolf)) flat3 = true;
+            else if (thick <= 1e-6 * (1.0 + amax) && m >= 4) {
+                // a sliver: its 3-D hull is the 2-D hull of the projection plus the points that stick out of
+                // the plane (Qhull keeps those as vertices; anything flatter than round-off it rejects outright)
+                flat3 = true;
+                if (tid == 0) { if (fabs(dmx) > tolf) S.hflag[gmx] = 2; if (fabs(dmn) > tolf) S.hflag[gmn] = 2; }   // 2 = kept, not a visited hull vertex
+                __syncthreads();
+            }
         }
     }
     if (!flat3) {
@@ -354,7 +371,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                 __syncthreads();
             }
             const int nxt = S.red_i[0];
-            const int seen = nxt >= 0 ? S.hflag[nxt] : 0;
+            const int seen = nxt >= 0 ? (S.hflag[nxt] == 1) : 0;
             __syncthreads();   // every thread has read red_i / hflag before thread 0 flags the next vertex
             if (nxt < 0 || nxt == iS || seen) break;
             {   // coincident with the start (shared mesh vertices produce exact duplicates): the loop is closed
@@ -412,46 +429,93 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
     }
 
     // ---- 1. candidate faces (contacts.py:44-52) in ascending face order ------------------------
+    // Runs of 256 faces whose culling box misses b's query cube are skipped outright.  Pass A tests the
+    // remaining faces and leaves one ballot word per (run, wavefront) in LDS -- no barrier per run;
+    // a block scan of the word popcounts gives every candidate its slot; pass B re-derives the triangle
+    // of the flagged faces and stores them.  Order = ascending face id, like nonzero(cand_mask).
     int ncand = 0, over = 0;
     Region reg;
     region_of(A.g, Bd.g, 1e-9, reg);
     const double *fbox = W.fch_box + (size_t)W.mesh_fch_off[A.mesh] * 6;
-    for (int base = 0; base < A.nf; base += NT) {
-        if (!box_hits(reg, fbox + (size_t)(base / NT) * 6)) continue;   // uniform: no centroid of this run is inside b's cube
-        const int f = base + tid;
-        int flag = 0;
-        double pqr[3][3];
-        if (f < A.nf) {
-            const double *c = W.fcent + (size_t)(A.foff + f) * 3;
-            double cb2[3];
-            for (int i = 0; i < 3; ++i) cb2[i] = R12[3 * i] * c[0] + R12[3 * i + 1] * c[1] + R12[3 * i + 2] * c[2] + t12[i];
-            const double lim = sB + 1e-9 * (1.0 + sB);
-            if (fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim) {
-                const int *fv = W.faces + (size_t)(A.foff + f) * 3;
-                double x[3] = {0, 0, 0};
-                for (int k = 0; k < 3; ++k) {
-                    to_frame(A.g, Bd.g, W.verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
-                    for (int i = 0; i < 3; ++i) x[i] += pqr[k][i];
-                }
-                for (int i = 0; i < 3; ++i) x[i] /= 3.0;
-                double phi, g[3], rad = 0.0;
-                query_sdf(Bd.g.shape, x, phi, g, true);
-                for (int k = 0; k < 3; ++k) {
-                    const double d[3] = {x[0] - pqr[k][0], x[1] - pqr[k][1], x[2] - pqr[k][2]};
-                    const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-                    if (r > rad) rad = r;
-                }
-                const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-                flag = (phi < rad + W.eps) && (gn > 1e-12);
+    const int nch = (A.nf + NT - 1) / NT, lane = tid & 63, wv = tid >> 6;
+    auto test_face = [&](int f, double pqr[3][3]) -> int {
+        const double *c = W.fcent + (size_t)(A.foff + f) * 3;
+        double cb2[3];
+        for (int i = 0; i < 3; ++i) cb2[i] = R12[3 * i] * c[0] + R12[3 * i + 1] * c[1] + R12[3 * i + 2] * c[2] + t12[i];
+        const double lim = sB + 1e-9 * (1.0 + sB);
+        if (!(fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim)) return 0;
+        const int *fv = W.faces + (size_t)(A.foff + f) * 3;
+        double x[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            to_frame(A.g, Bd.g, W.verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
+            for (int i = 0; i < 3; ++i) x[i] += pqr[k][i];
+        }
+        for (int i = 0; i < 3; ++i) x[i] /= 3.0;
+        double phi, g[3], rad = 0.0;
+        query_sdf(Bd.g.shape, x, phi, g, true);
+        for (int k = 0; k < 3; ++k) {
+            const double d[3] = {x[0] - pqr[k][0], x[1] - pqr[k][1], x[2] - pqr[k][2]};
+            const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            if (r > rad) rad = r;
+        }
+        const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        return (phi < rad + W.eps) && (gn > 1e-12);
+    };
+    if (nch <= MAX_CH) {
+        unsigned long long *words = reinterpret_cast<unsigned long long *>(S.hp);   // [nch][4]
+        for (int e = tid; e < nch * 4; e += NT) words[e] = 0ull;
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            if (!box_hits(reg, fbox + (size_t)ch * 6)) continue;
+            const int f = ch * NT + tid;
+            double pqr[3][3];
+            const int flag = f < A.nf ? test_face(f, pqr) : 0;
+            const unsigned long long w = __ballot(flag);
+            if (lane == 0 && w) words[ch * 4 + wv] = w;
+        }
+        __syncthreads();
+        // exclusive scan of the popcounts: thread t owns words [t*per, (t+1)*per)
+        const int per = (nch * 4 + NT - 1) / NT;
+        int mine = 0;
+        for (int e = tid * per; e < (tid + 1) * per && e < nch * 4; ++e) mine += __popcll(words[e]);
+        S.red_i[tid] = mine;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int t = 0; t < NT; ++t) { const int v = S.red_i[t]; S.red_i[t] = run; run += v; } S.wave_tot[0] = run; }
+        __syncthreads();
+        ncand = S.wave_tot[0];
+        {
+            int run = S.red_i[tid];
+            for (int e = tid * per; e < (tid + 1) * per && e < nch * 4; ++e) { S.woff[e] = run; run += __popcll(words[e]); }
+        }
+        __syncthreads();
+        if (ncand > 0)
+            for (int ch = 0; ch < nch; ++ch) {
+                const unsigned long long w = words[ch * 4 + wv];
+                if (!((w >> lane) & 1ull)) continue;
+                const int slot = S.woff[ch * 4 + wv] + __popcll(w & ((1ull << lane) - 1ull));
+                if (slot >= MC) continue;
+                const int f = ch * NT + tid;
+                double pqr[3][3];
+                test_face(f, pqr);
+                cface[slot] = f;
+                for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
             }
-        }
-        if (!__syncthreads_or(flag)) continue;
-        const int slot = compact_slot(flag, ncand, S);
-        if (slot >= 0 && slot < MC) {
-            cface[slot] = f;
-            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
-        }
         if (ncand > MC) { over |= 1; ncand = MC; }
+        __syncthreads();
+    } else {
+        for (int base = 0; base < A.nf; base += NT) {
+            if (!box_hits(reg, fbox + (size_t)(base / NT) * 6)) continue;
+            const int f = base + tid;
+            double pqr[3][3];
+            const int flag = f < A.nf ? test_face(f, pqr) : 0;
+            if (!__syncthreads_or(flag)) continue;
+            const int slot = compact_slot(flag, ncand, S);
+            if (slot >= 0 && slot < MC) {
+                cface[slot] = f;
+                for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
+            }
+            if (ncand > MC) { over |= 1; ncand = MC; }
+        }
     }
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return; }
     __syncthreads();
@@ -533,13 +597,24 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         if (nmov > 1024) { over |= 2; nmov = 1024; }
         __syncthreads();
     }
+    // the mover owned by this thread (if any) stays in registers for the remaining iterations
+    Cand m0;
+    const int k0 = tid < nmov ? S.hidx[tid] : -1;
+    int alive0 = k0 >= 0;
+    if (alive0) load_c(m0, k0);
     for (int iter = 1; iter < 32 && nmov > 0; ++iter) {
         float gam[MAX_CPT]; int ind[MAX_CPT];
-        int any_pen = 0, moving = 0, q = 0, pen;
-        for (int j = tid; j < nmov; j += NT, ++q) {
+        int any_pen = 0, moving = 0, q = 1, pen;
+        gam[0] = 0.0f; ind[0] = 0;
+        if (alive0) {
+            eval_c(m0, iter, gam[0], ind[0], pen);
+            any_pen |= pen; moving |= gam[0] != 0.0f;
+            if (gam[0] == 0.0f) alive0 = 0;     // froze: x no longer changes, every later evaluation repeats this one
+        }
+        for (int j = tid + NT; j < nmov; j += NT, ++q) {
             const int k = S.hidx[j];
             gam[q] = 0.0f; ind[q] = 0;
-            if (cstate[k] < 0) continue;          // froze earlier
+            if (cstate[k] < 0) continue;
             Cand c; load_c(c, k);
             eval_c(c, iter, gam[q], ind[q], pen);
             any_pen |= pen; moving |= gam[q] != 0.0f;
@@ -551,13 +626,15 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         int vote = 0;
         for (int w = 0; w < NT / 64; ++w) vote |= S.vote[iter & 1][w];
         if (!(vote & 1) || (vote & 2)) break;   // all gamma == 0, or a penetrating point (contacts.py:74-77)
-        q = 0;
-        for (int j = tid; j < nmov; j += NT, ++q) {
+        if (gam[0] != 0.0f) apply_c(m0, gam[0], ind[0]);
+        q = 1;
+        for (int j = tid + NT; j < nmov; j += NT, ++q) {
             if (gam[q] == 0.0f) continue;
             const int k = S.hidx[j];
             Cand c; load_c(c, k); apply_c(c, gam[q], ind[q]); store_c(c, k);
         }
     }
+    if (k0 >= 0) store_c(m0, k0);
     __syncthreads();
 
     STAMP(2);

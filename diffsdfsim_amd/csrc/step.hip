@@ -237,7 +237,9 @@ int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspac
     hipLaunchKernelGGL(integrate_kernel, dim3(W->B), dim3(64), 0, stream, *W);
     NewContacts N;
     N.nc = W->n_nc; N.body = W->n_body; N.face = W->n_face; N.abc = W->n_abc; N.geom = W->n_geom;
+    if (W->ev_np_start) hipEventRecord((hipEvent_t)W->ev_np_start, stream);
     rc = dss::launch_find_contacts(*W, N.nc, N.body, N.face, N.abc, N.geom, stream);
+    if (W->ev_np_stop) hipEventRecord((hipEvent_t)W->ev_np_stop, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(decide_kernel, dim3(W->B), dim3(64), 0, stream, *W, N);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;

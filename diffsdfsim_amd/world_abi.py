@@ -38,7 +38,7 @@ FIELDS = [
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
     ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"), ("tp_flags", "pi"),
-    ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("dbg_stamps", "ev"),
+    ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("ev_np_start", "ev"), ("ev_np_stop", "ev"), ("dbg_stamps", "ev"),
 ]
 
 

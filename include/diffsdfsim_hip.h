@@ -179,6 +179,7 @@ typedef struct DssWorld {
     int *tp_flags;   /* bit 0: the sub-step ended with a time-of-contact event, bit 1: its dt_ used last_dt (world.py:253-257) */
     /* optional hipEvent_t pair recorded around the LCP launch of dss_step_attempt (bench roofline) */
     void *ev_lcp_start, *ev_lcp_stop;
+    void *ev_np_start, *ev_np_stop;   /* same, around the contact-detection launches */
     /* optional [grid of narrowphase][8] phase time stamps (diagnostic runs only; NULL in production) */
     long long *dbg_stamps;
 } DssWorld;
