@@ -7,7 +7,7 @@
 // partial pivoting is implicit (`step` = elimination step at which a row served as pivot).
 //   row i, before it is a pivot:   a[k] (k < current step) = multiplier l_ik
 //   row i, once pivot at step s:   a[j] (j > s) = U_sj,  a[s] = 1 / U_ss
-// Pivot choice: largest |a_ik| among unused rows, compared on the top 58 bits (ties -> lowest lane).
+// Pivot choice: largest |a_ik| among unused rows, compared in float precision (ties -> lowest lane).
 #pragma once
 #include "wave_utils.h"
 
@@ -31,14 +31,28 @@ __device__ __forceinline__ int wave_uniform(int v)
     return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+// max over the 64 lanes of a 32-bit key, result uniform.  gfx950: DPP row shifts + row broadcasts (the
+// classic GCN reduction ladder: shr 1,2,3 | shr 4 | shr 8 | bcast15 | bcast31, total in lane 63) instead of
+// six LDS-crossbar shuffles.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, WAVE);
-        v = w > v ? w : v;
-    }
+#if defined(DSS_EMU)
+    for (int o = WAVE / 2; o > 0; o >>= 1) { const unsigned w = __shfl_xor(v, o, WAVE); v = w > v ? w : v; }
     return v;
+#else
+#define DSS_DPP_MAX(ctrl, rmask, bmask)                                                                       \
+    { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, bmask, false);   \
+      v = t > v ? t : v; }
+    DSS_DPP_MAX(0x111, 0xf, 0xf)   // row_shr:1
+    DSS_DPP_MAX(0x112, 0xf, 0xf)   // row_shr:2
+    DSS_DPP_MAX(0x113, 0xf, 0xf)   // row_shr:3
+    DSS_DPP_MAX(0x114, 0xf, 0xe)   // row_shr:4
+    DSS_DPP_MAX(0x118, 0xf, 0xc)   // row_shr:8
+    DSS_DPP_MAX(0x142, 0xa, 0xf)   // row_bcast:15
+    DSS_DPP_MAX(0x143, 0xc, 0xf)   // row_bcast:31
+#undef DSS_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#endif
 }
 __device__ __forceinline__ int lane_of_step(int step, int k)
 {
@@ -82,14 +96,14 @@ template <int N> __device__ __forceinline__ void regk_factor(RegK<N> &R)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const bool unused = R.step == N;
-        unsigned long long key = 0ull;
+        unsigned key = 0u;
         if (unused) {
-            const double v = fabs(R.a[k]);
-            key = ((unsigned long long)__double_as_longlong(v) & ~63ull) | (unsigned long long)(63 - lane);
-            key |= 1ull << 63;   // any unused row beats "no row" even when its entry is +0
+            // |a_ik| as float (monotone, clamped to the float range), low 6 bits replaced by 63 - lane
+            const float vf = (float)fmin(fabs(R.a[k]), 3.0e38);
+            key = ((__float_as_uint(vf) >> 1) & ~63u) | (unsigned)(63 - lane) | 0x80000000u;
         }
-        key = wave_max_u64(key);
-        const int p = wave_uniform(63 - (int)(key & 63ull));
+        key = wave_max_u32(key);
+        const int p = wave_uniform(63 - (int)(key & 63u));
         if (lane == p) R.step = k;
         const double inv = 1.0 / wave_bcast(R.a[k], p);
         const bool upd = R.step == N;

@@ -100,16 +100,16 @@ template <int ND> __device__ inline void f_rows(double mu, const double *z, doub
     for (int k = 1; k <= 2 * ND; ++k) { fz[k] = z[2 * ND + 1]; sum += z[k]; }
     fz[2 * ND + 1] = mu * z[0] - sum;
 }
-// u = (F_c + diag(a))^-1 r   (arrow block, closed form)
-template <int ND> __device__ inline void w_apply(double mu, const double *a, const double *r, double *u)
+// u = (F_c + diag(a))^-1 r   (arrow block, closed form).  ia = 1/a = z/s (the IPM's d), ag = a of the cone row.
+template <int ND> __device__ inline void w_apply(double mu, const double *ia, double ag, const double *r, double *u)
 {
-    double den = a[2 * ND + 1], num = r[2 * ND + 1] - mu * r[0] / a[0];
+    double den = ag, num = r[2 * ND + 1] - mu * r[0] * ia[0];
 #pragma unroll
-    for (int k = 1; k <= 2 * ND; ++k) { den += 1.0 / a[k]; num += r[k] / a[k]; }
+    for (int k = 1; k <= 2 * ND; ++k) { den += ia[k]; num += r[k] * ia[k]; }
     const double ug = num / den;
-    u[0] = r[0] / a[0];
+    u[0] = r[0] * ia[0];
 #pragma unroll
-    for (int k = 1; k <= 2 * ND; ++k) u[k] = (r[k] - ug) / a[k];
+    for (int k = 1; k <= 2 * ND; ++k) u[k] = (r[k] - ug) * ia[k];
     u[2 * ND + 1] = ug;
 }
 // w = sum_rows sign_r u_r D_r  ( G_c^T u = P_c w )
@@ -123,18 +123,18 @@ template <int ND> __device__ inline void w_vec(const Geo<ND> &g, const double *u
         w[j] = acc;
     }
 }
-// C_c with G_c^T (F_c + diag(a))^-1 G_c = P_c C_c P_c^T
-template <int ND> __device__ inline void c_mat(const Geo<ND> &g, const double *a, double *C)
+// C_c with G_c^T (F_c + diag(a))^-1 G_c = P_c C_c P_c^T   (ia = 1/a, ag = a of the cone row)
+template <int ND> __device__ inline void c_mat(const Geo<ND> &g, const double *ia, double ag, double *C)
 {
-    double den = a[2 * ND + 1], bv[3] = {0, 0, 0};
-    const double ian = 1.0 / a[0];
+    double den = ag, bv[3] = {0, 0, 0};
+    const double ian = ia[0];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) C[3 * i + j] = ian * g.D[0][i] * g.D[0][j];
 #pragma unroll
     for (int k = 1; k <= ND; ++k) {
-        const double i1 = 1.0 / a[k], i2 = 1.0 / a[ND + k];
+        const double i1 = ia[k], i2 = ia[ND + k];
         den += i1 + i2;
         const double al = i1 + i2, be = i1 - i2;
 #pragma unroll
@@ -464,9 +464,9 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 #pragma unroll
         for (int r = 0; r < NR; ++r) { a[r] = 1.0; t[r] = 0.0; }
         t[0] = -g.hn;  // rz - rs/d with rz = -h, rs = 0
-        w_apply<ND>(g.mu, a, t, u);
+        w_apply<ND>(g.mu, a, 1.0, t, u);
         w_vec<ND>(g, u, w);
-        c_mat<ND>(g, a, C);
+        c_mat<ND>(g, a, 1.0, C);
         // the C matrices go to K first; stash w in the (not yet used) ds scratch
 #pragma unroll
         for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
@@ -505,7 +505,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             r[0] -= g.hn;
 #pragma unroll
             for (int q = 0; q < NR; ++q) a[q] = 1.0;
-            w_apply<ND>(g.mu, a, r, u);
+            w_apply<ND>(g.mu, a, 1.0, r, u);
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 cz[(size_t)q * maxc + c] = u[q];
@@ -548,13 +548,13 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
                 crz[(size_t)q * maxc + c] = rz;
                 acc_rz += rz * rz;
                 acc_sz += s[q] * z[q];
-                a[q] = s[q] / z[q];
+                a[q] = z[q] / s[q];   // 1/a = d
                 t[q] = rz - s[q];  // rz - rs/d with rs = z
             }
             w_vec<ND>(g, z, w);
 #pragma unroll
             for (int j = 0; j < 3; ++j) L.cw[6 * c + j] = w[j];
-            w_apply<ND>(g.mu, a, t, u);
+            w_apply<ND>(g.mu, a, s[NR - 1] / z[NR - 1], t, u);
             w_vec<ND>(g, u, w);
 #pragma unroll
             for (int j = 0; j < 3; ++j) L.cw[6 * c + 3 + j] = w[j];
@@ -600,8 +600,8 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             load_geo<ND>(g, cop, cbody, maxc, c);
             double a[NR], C[9];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) a[q] = cs[(size_t)q * maxc + c] / cz[(size_t)q * maxc + c];
-            c_mat<ND>(g, a, C);
+            for (int q = 0; q < NR; ++q) a[q] = cz[(size_t)q * maxc + c] / cs[(size_t)q * maxc + c];
+            c_mat<ND>(g, a, cs[(size_t)(NR - 1) * maxc + c] / cz[(size_t)(NR - 1) * maxc + c], C);
 #pragma unroll
             for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
         }
@@ -629,13 +629,13 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 s[q] = cs[(size_t)q * maxc + c]; z[q] = cz[(size_t)q * maxc + c];
-                a[q] = s[q] / z[q];
+                a[q] = z[q] / s[q];
                 r[q] += crz[(size_t)q * maxc + c] - s[q];
             }
-            w_apply<ND>(g.mu, a, r, u);
+            w_apply<ND>(g.mu, a, s[NR - 1] / z[NR - 1], r, u);
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
-                const double dz = u[q], ds = (-z[q] - dz) / (z[q] / s[q]);
+                const double dz = u[q], ds = (-z[q] - dz) / a[q];
                 cdz[(size_t)q * maxc + c] = dz;
                 cds[(size_t)q * maxc + c] = ds;
                 stz.add(z[q], dz);
@@ -658,15 +658,16 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         for (int c = lane; c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
-            double a[NR], t[NR], u[NR], w[3];
+            double a[NR], t[NR], u[NR], w[3], ag = 1.0;
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 const double s = cs[(size_t)q * maxc + c], z = cz[(size_t)q * maxc + c];
                 const double rs2 = (-mu * sig + cds[(size_t)q * maxc + c] * cdz[(size_t)q * maxc + c]) / s;
-                a[q] = s / z;
-                t[q] = rs2 / (z / s);
+                a[q] = z / s;
+                t[q] = rs2 / a[q];
+                if (q == NR - 1) ag = s / z;
             }
-            w_apply<ND>(g.mu, a, t, u);
+            w_apply<ND>(g.mu, a, ag, t, u);
             w_vec<ND>(g, u, w);
 #pragma unroll
             for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = w[j];
@@ -692,14 +693,14 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             for (int q = 0; q < NR; ++q) {
                 s[q] = cs[(size_t)q * maxc + c]; z[q] = cz[(size_t)q * maxc + c];
                 rs2[q] = (-mu * sig + cds[(size_t)q * maxc + c] * cdz[(size_t)q * maxc + c]) / s[q];
-                a[q] = s[q] / z[q];
-                r[q] -= rs2[q] / (z[q] / s[q]);
+                a[q] = z[q] / s[q];
+                r[q] -= rs2[q] / a[q];
             }
-            w_apply<ND>(g.mu, a, r, u);
+            w_apply<ND>(g.mu, a, s[NR - 1] / z[NR - 1], r, u);
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 const double dz = cdz[(size_t)q * maxc + c] + u[q];
-                const double ds = cds[(size_t)q * maxc + c] + (-rs2[q] - u[q]) / (z[q] / s[q]);
+                const double ds = cds[(size_t)q * maxc + c] + (-rs2[q] - u[q]) / a[q];
                 cdz[(size_t)q * maxc + c] = dz;
                 cds[(size_t)q * maxc + c] = ds;
                 stz2.add(z[q], dz);
@@ -763,8 +764,8 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
         double a[NR], C[9];
 #pragma unroll
         for (int q = 0; q < NR; ++q)  // d = clamp(lam)/clamp(slack), lcp.py:176
-            a[q] = fmax(slack[(size_t)q * maxc + c], 1e-8) / fmax(lam[(size_t)q * maxc + c], 1e-8);
-        c_mat<ND>(g, a, C);
+            a[q] = fmax(lam[(size_t)q * maxc + c], 1e-8) / fmax(slack[(size_t)q * maxc + c], 1e-8);
+        c_mat<ND>(g, a, fmax(slack[(size_t)(NR - 1) * maxc + c], 1e-8) / fmax(lam[(size_t)(NR - 1) * maxc + c], 1e-8), C);
 #pragma unroll
         for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
     }
@@ -800,12 +801,12 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             l[q] = lam[(size_t)q * maxc + c];
-            a[q] = fmax(slack[(size_t)q * maxc + c], 1e-8) / fmax(l[q], 1e-8);
+            a[q] = fmax(l[q], 1e-8) / fmax(slack[(size_t)q * maxc + c], 1e-8);
         }
         rel_vel<ND>(dx, g, vrx);
         rel_vel<ND>(zx, g, vrz);
         g_rows<ND>(g, vrx, r);
-        w_apply<ND>(g.mu, a, r, dl);  // dlam = W G dx
+        w_apply<ND>(g.mu, a, fmax(slack[(size_t)(NR - 1) * maxc + c], 1e-8) / fmax(l[NR - 1], 1e-8), r, dl);  // dlam = W G dx
         // directions
 #pragma unroll
         for (int j = 0; j < 3; ++j) dcop[(size_t)j * maxc + c] = dl[0] * vrz[j] + l[0] * vrx[j];
@@ -839,6 +840,14 @@ inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
 }  // namespace
 
 #if defined(DSS_DIAG)
+__global__ void selftest_wave_max_kernel(const unsigned *in, unsigned *out)
+{
+    out[blockIdx.x] = dss::wave_max_u32(in[blockIdx.x * 64 + threadIdx.x]);
+}
+extern "C" void dss_diag_wave_max(const unsigned *in, unsigned *out, int n, void *stream)
+{
+    hipLaunchKernelGGL(selftest_wave_max_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, in, out);
+}
 __global__ void set_lcp_stamps_kernel(long long *p) { g_lcp_stamps = p; }
 extern "C" void dss_diag_set_lcp_stamps(long long *p, void *stream)
 {

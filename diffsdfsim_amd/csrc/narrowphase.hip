@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
     const int j = i + 1 + rem;
     int *flag = W.ovl + ((size_t)sc * W.nb + i) * W.nb + j;
     const int dp_ij = i * (W.nb - 1) + (j - 1), dp_ji = j * (W.nb - 1) + i;
+    __shared__ unsigned long long s_mask[NT / 64];
     int ok = !W.no_contact[i * W.nb + j];
     if (ok) {
         BodyD A, Bd;
@@ -112,17 +113,30 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
             Region reg;
             region_of(src.g, dst.g, 1e-9, reg);
             const double *vbox = W.vch_box + (size_t)W.mesh_vch_off[src.mesh] * 6;
+            const int nch = (src.nv + NT - 1) / NT;
             int found = 0;
-            for (int base = 0; base < src.nv && !found; base += NT) {
-                if (!box_hits(reg, vbox + (size_t)(base / NT) * 6)) continue;   // uniform: no vertex of this run can be inside
-                int hit = 0;
-                const int v = base + tid;
-                if (v < src.nv) {
-                    double p[3];
-                    to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
-                    hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+            // culling boxes tested in parallel, 256 runs at a time; only runs that can reach dst's cube are walked
+            for (int cb0 = 0; cb0 < nch && !found; cb0 += NT) {
+                const int ch = cb0 + tid;
+                const unsigned long long hitm = __ballot(ch < nch && box_hits(reg, vbox + (size_t)ch * 6));
+                if ((tid & 63) == 0) s_mask[tid >> 6] = hitm;
+                __syncthreads();
+                for (int w = 0; w < NT / 64 && !found; ++w) {
+                    unsigned long long m = s_mask[w];
+                    while (m && !found) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int v = (cb0 + 64 * w + b) * NT + tid;
+                        int hit = 0;
+                        if (v < src.nv) {
+                            double p[3];
+                            to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
+                            hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+                        }
+                        found = __syncthreads_or(hit);
+                    }
                 }
-                found = __syncthreads_or(hit);
+                __syncthreads();
             }
             ok = found;
         }
@@ -462,22 +476,28 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
     if (nch <= MAX_CH) {
-        unsigned long long *words = reinterpret_cast<unsigned long long *>(S.hp);   // [nch][4]
-        for (int e = tid; e < nch * 4; e += NT) words[e] = 0ull;
+        // runs that can hold a candidate: tested in parallel (one culling box per thread), kept in order
+        int npass = 0;
+        for (int base = 0; base < nch; base += NT) {
+            const int ch = base + tid;
+            const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6);
+            const int slot = compact_slot(hit, npass, S);
+            if (slot >= 0) S.hidx[slot] = ch;
+        }
+        unsigned long long *words = reinterpret_cast<unsigned long long *>(S.hp);   // [npass][4]
         __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            if (!box_hits(reg, fbox + (size_t)ch * 6)) continue;
-            const int f = ch * NT + tid;
+        for (int i = 0; i < npass; ++i) {
+            const int f = S.hidx[i] * NT + tid;
             double pqr[3][3];
             const int flag = f < A.nf ? test_face(f, pqr) : 0;
             const unsigned long long w = __ballot(flag);
-            if (lane == 0 && w) words[ch * 4 + wv] = w;
+            if (lane == 0) words[i * 4 + wv] = w;
         }
         __syncthreads();
         // exclusive scan of the popcounts: thread t owns words [t*per, (t+1)*per)
-        const int per = (nch * 4 + NT - 1) / NT;
+        const int nw = npass * 4, per = (nw + NT - 1) / NT;
         int mine = 0;
-        for (int e = tid * per; e < (tid + 1) * per && e < nch * 4; ++e) mine += __popcll(words[e]);
+        for (int e = tid * per; e < (tid + 1) * per && e < nw; ++e) mine += __popcll(words[e]);
         S.red_i[tid] = mine;
         __syncthreads();
         if (tid == 0) { int run = 0; for (int t = 0; t < NT; ++t) { const int v = S.red_i[t]; S.red_i[t] = run; run += v; } S.wave_tot[0] = run; }
@@ -485,20 +505,20 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         ncand = S.wave_tot[0];
         {
             int run = S.red_i[tid];
-            for (int e = tid * per; e < (tid + 1) * per && e < nch * 4; ++e) { S.woff[e] = run; run += __popcll(words[e]); }
+            for (int e = tid * per; e < (tid + 1) * per && e < nw; ++e) { S.woff[e] = run; run += __popcll(words[e]); }
         }
         __syncthreads();
         if (ncand > 0)
-            for (int ch = 0; ch < nch; ++ch) {
-                const unsigned long long w = words[ch * 4 + wv];
+            for (int i = 0; i < npass; ++i) {
+                const unsigned long long w = words[i * 4 + wv];
                 if (!((w >> lane) & 1ull)) continue;
-                const int slot = S.woff[ch * 4 + wv] + __popcll(w & ((1ull << lane) - 1ull));
+                const int slot = S.woff[i * 4 + wv] + __popcll(w & ((1ull << lane) - 1ull));
                 if (slot >= MC) continue;
-                const int f = ch * NT + tid;
+                const int f = S.hidx[i] * NT + tid;
                 double pqr[3][3];
                 test_face(f, pqr);
                 cface[slot] = f;
-                for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) CB(3 * k + i, slot) = pqr[k][i];
+                for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
             }
         if (ncand > MC) { over |= 1; ncand = MC; }
         __syncthreads();
