@@ -33,6 +33,22 @@ def lcp_algorithmic_bytes(nb, neq, fd, nc_per_scene):
     return float(np.sum(per_scene_fixed + per_contact * np.asarray(nc_per_scene, np.float64)))
 
 
+def detect_algorithmic_bytes(E):
+    """Compulsory traffic of one contact-detection launch group (overlap + narrow phase + compaction), bytes:
+    per active directed pair  culling boxes of mesh a (48 B/run) + centroid/radius of the faces in the runs that
+    pass (32 B/face) + triangle of every candidate (3 x 24 B + 12 B) + its Frank-Wolfe record written and read once
+    (15 x 8 B x 2) + contacts out (14 x 8 B), plus both bodies' state."""
+    st = E.get("pc_stats").astype(np.float64)
+    cnt = E.get("pc_count").astype(np.float64)
+    mesh_nf = E.get("mesh_nf")[E.get("mesh_id")].astype(np.float64)          # [B, nb]
+    nb = E.nb
+    a_of = np.repeat(np.arange(nb), nb - 1)                                   # mesh body of directed pair dp
+    nch = np.ceil(mesh_nf[:, a_of] / 256.0)
+    active = st[:, :, 0] > 0
+    per_pair = nch * 48 + st[:, :, 0] * 256 * 32 + st[:, :, 1] * (84 + 240) + cnt * 112 + 2 * 20 * 8
+    return float((per_pair * active).sum())
+
+
 def cpu_baseline(E, n_sample, threads):
     """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of
     batch.py / lcp.py) on the operands the GPU just solved, for a bounded sample of scenes."""
@@ -121,7 +137,7 @@ def main():
         a.record(); b.record()
         return a, b
 
-    pool = [fresh_pair() for _ in range(4 * K + 64)]
+    pool = [fresh_pair() for _ in range(8 * K + 128)]
     torch.cuda.synchronize()
     lo = E.arr["nsub"].clone()
     nc_hist = []
@@ -134,11 +150,13 @@ def main():
         E._check(L.dss_step_begin(ctypes.byref(E.W), E.be.stream()), "dss_step_begin")
         n, k = E.B, 0
         while n > 0:
-            a, b = pool[len(ev)]
+            a, b = pool[2 * len(ev)]
+            c, d = pool[2 * len(ev) + 1]
             E.W.ev_lcp_start, E.W.ev_lcp_stop = a.cuda_event, b.cuda_event
+            E.W.ev_np_start, E.W.ev_np_stop = c.cuda_event, d.cuda_event
             E._check(L.dss_step_attempt(ctypes.byref(E.W), ctypes.c_void_p(E.be.ptr(E.lcp_ws)),
                                         ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream()), "dss_step_attempt")
-            ev.append((a, b))
+            ev.append((a, b, c, d))
             n = E.be.read_int(E.arr["n_active"])
             k += 1
         return k
@@ -150,7 +168,7 @@ def main():
     att = 0
     for _ in range(K):
         att += timed_step()
-    E.W.ev_lcp_start, E.W.ev_lcp_stop = None, None
+    E.W.ev_lcp_start, E.W.ev_lcp_stop, E.W.ev_np_start, E.W.ev_np_stop = None, None, None, None
     loss_adjoint()
     E.adj["lo_slot"].copy_(lo)
     E.backward_sweep(att)
@@ -169,11 +187,22 @@ def main():
 
     if rank != 0:
         return
-    lcp_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    lcp_ms = np.array([a.elapsed_time(b) for a, b, c, d in ev])
+    det_ms = np.array([c.elapsed_time(d) for a, b, c, d in ev])
     nc = E.get("nc")
-    algo = lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc)
-    ach = algo / (lcp_ms.mean() * 1e-3) / 1e9
     overflow = int(E.get("overflow").max())
+
+    def roof(kernel, ms, algo, note):
+        ach = algo / (ms.mean() * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": float(ms.mean()), "launches": len(ms),
+                "algorithmic_bytes_per_launch": algo, "note": note}
+
+    r_lcp = roof("lcp_contact_forward_kernel<4>", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
+                 "one wavefront per scene, KKT in registers/LDS: bound by serial fp64 latency, not HBM (DESIGN.md section 5)")
+    r_det = roof("narrowphase_kernel (+overlap_kernel, compact_contacts_kernel)", det_ms, detect_algorithmic_bytes(E),
+                 "Frank-Wolfe / SDF evaluation: bound by fp64 div/sqrt chains and block barriers, not HBM (DESIGN.md section 5)")
+    dominant, other = (r_det, r_lcp) if det_ms.mean() >= lcp_ms.mean() else (r_lcp, r_det)
     res = {
         "metric": "sim steps/sec (fwd+bwd), 1024 batched 3D scenes x 8 SDF bodies",
         "value": world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -182,13 +211,11 @@ def main():
         "config": {"workload": "configs[2]: floor + %d-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep"
                                % (args.nbox, B, K),
                    "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
-                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()), "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
+                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()),
+                   "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
                    "parallelism": "scene-sharded x%d, no collective in step" % world},
-        "roofline": {"bound": "hbm", "kernel": "lcp_contact_forward_kernel<4>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "avg_launch_ms": float(lcp_ms.mean()), "launches": len(lcp_ms), "algorithmic_bytes_per_launch": algo,
-                     "note": "latency-bound (one wavefront per scene, 1 wave/SIMD at B=1024); see DESIGN.md"},
+        "roofline": dominant, "roofline_second_kernel": other,
     }
     if not args.no_cpu:
         threads = min(os.cpu_count() or 1, args.cpu_sample)

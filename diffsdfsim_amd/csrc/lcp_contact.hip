@@ -280,8 +280,20 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
     const int r = lane >> 2, grp = lane & 3;
     const int br = r / 6, rr = r % 6, bc = grp >> 1, kind = grp & 1;
     const double sgn = (br == bc) ? 1.0 : -1.0;
-    if (lane < 48)
+    // contacts arrive grouped by (body1, body2) (detection emits them pair by pair): the 12x12 local sum of a
+    // run is kept in registers (3 values per lane) and added to K once per run instead of once per contact
+    if (lane < 48) {
+        int pb1 = -1, pb2 = -1;
+        double acc[3] = {0.0, 0.0, 0.0};
+        auto flush = [&]() {
+            if (pb1 < 0) return;
+            const int row = 6 * (br ? pb2 : pb1) + rr, col = 6 * (bc ? pb2 : pb1) + 3 * kind;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { L.K[row * lda + col + j] += sgn * acc[j]; acc[j] = 0.0; }
+        };
         for (int c = 0; c < nc; ++c) {
+            const int b1 = cbody[c], b2 = cbody[L.maxc + c];
+            if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
             const double *C = L.cw + 9 * c;
             const double *pr = L.pbuf + 6 * c + 3 * br, *pc = L.pbuf + 6 * c + 3 * bc;
             double a[3], o[3];
@@ -295,10 +307,11 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             }
             if (kind == 0) cross3(pc, a, o);
             else { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
-            const int row = 6 * cbody[br * L.maxc + c] + rr, col = 6 * cbody[bc * L.maxc + c] + 3 * kind;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) L.K[row * lda + col + j] += sgn * o[j];
+            for (int j = 0; j < 3; ++j) acc[j] += o[j];
         }
+        flush();
+    }
     __syncthreads();
 }
 

@@ -521,6 +521,7 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
                 for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
             }
         if (ncand > MC) { over |= 1; ncand = MC; }
+        if (tid == 0) { W.pc_stats[((size_t)sc * np + dp) * 2] = npass; W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = ncand; }
         __syncthreads();
     } else {
         for (int base = 0; base < A.nf; base += NT) {

@@ -32,7 +32,7 @@ FIELDS = [
     ("Mblk", "pd"), ("pvec", "pd"), ("cop", "pd"), ("x", "pd"), ("lam", "pd"), ("slack", "pd"), ("nu", "pd"),
     ("cop_body", "pi"), ("lcp_iters", "pi"), ("lcp_status", "pi"),
     ("ovl", "pi"), ("pair_list", "pi"), ("n_pairs", "pi"), ("invalid", "pi"), ("overflow", "pi"),
-    ("pc_count", "pi"), ("pc_face", "pi"), ("pc_abc", "pd"), ("pc_geom", "pd"),
+    ("pc_count", "pi"), ("pc_stats", "pi"), ("pc_face", "pi"), ("pc_abc", "pd"), ("pc_geom", "pd"),
     ("cand_face", "pi"), ("cand_state", "pi"), ("cand_buf", "pd"),
     ("max_sub", "i"),
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
@@ -70,7 +70,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
         "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
         "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
         "ovl": (B, nb, nb), "pair_list": (B * npair,), "n_pairs": (2,), "invalid": (B,), "overflow": (B,),
-        "pc_count": (B, npair), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
+        "pc_count": (B, npair), "pc_stats": (B, npair, 2), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
         "pc_geom": (B, npair, 10, max_pc),
         "cand_face": (B, npair, 2, max_cand), "cand_state": (B, npair, max_cand),
         "cand_buf": (B, npair, CAND_FIELDS, max_cand),

@@ -166,6 +166,7 @@ typedef struct DssWorld {
     int *invalid;            /* [B] penetration > tol found in this attempt */
     int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
+    int *pc_stats;           /* [B][npairs][2] work done for the pair: face runs tested, candidate faces (bench accounting) */
     int *pc_face;            /* [B][npairs][max_pc] */
     double *pc_abc;          /* [B][npairs][3][max_pc] */
     double *pc_geom;         /* [B][npairs][10][max_pc] */
