@@ -221,6 +221,16 @@ int dss_find_contacts(const DssWorld *W, void *stream)
     return dss::launch_find_contacts(*W, W->nc, W->c_body, W->c_face, W->c_abc, W->c_geom, (hipStream_t)stream);
 }
 
+int dss_solve_dynamics(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream_)
+{
+    int rc = check_world(W);
+    if (rc) return rc;
+    hipLaunchKernelGGL(assemble_kernel, dim3(W->B), dim3(64), 0, (hipStream_t)stream_, *W);
+    return dss_lcp_contact_forward(W->Mblk, W->pvec, W->Je, W->b_eq, W->cop, W->cop_body, W->nc, W->active, W->B, W->nb,
+                                   W->neq, W->maxc, W->fric_dirs, 1e-12, 3, W->lcp_max_iter, W->x, W->lam, W->slack, W->nu,
+                                   W->lcp_iters, W->lcp_status, lcp_workspace, lcp_workspace_bytes, stream_);
+}
+
 int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream_)
 {
     int rc = check_world(W);

@@ -3,3 +3,4 @@ from .constraints import RotConstraint3D, TotalConstraint3D, XConstraint, YConst
 from .forces import ExternalForce3D, Gravity3D  # noqa: F401
 from .utils import Defaults3D  # noqa: F401
 from .world import BatchWorld3D, World3D, run_world  # noqa: F401
+from .engines import Engine, HipPdipmEngine, PdipmEngine  # noqa: F401

@@ -106,6 +106,8 @@ class World3D(BatchWorld3D):
                  device=None, max_substeps=1024):
         if post_stab or stop_contact_grad or stop_friction_grad or detach_contact_b2:
             raise NotImplementedError("post_stab / stop_*_grad / detach_contact_b2 are not built on the HIP path yet")
+        from . import engines as engines_module
+        self.engine_plugin = engine() if isinstance(engine, type) else getattr(engines_module, engine)()
         self.bodies = bodies
         self.vec_len = 6
         nb = len(bodies)

@@ -197,6 +197,10 @@ int dss_step_begin(const DssWorld *W, void *stream);
 /* One attempt for all active scenes.  Enqueues: assemble -> LCP -> integrate -> detect -> decide.
  * After it completes W->n_active[0] holds the number of scenes that still have t < t_end.      */
 int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream);
+/* Engine plug-in (boundary B2), PdipmEngine.solve_dynamics(world, dt) (engines.py:31-83) for every scene with
+ * active[s] != 0: assembles from the current state / contacts with dt = dt_try[s] and solves; the new velocities
+ * are -W->x.  Nothing else is modified (no integration, no detection). */
+int dss_solve_dynamics(const DssWorld *W, void *lcp_workspace, size_t lcp_workspace_bytes, void *stream);
 /* Contact detection only, at the current pose (World.__init__, world.py:96-100). */
 int dss_find_contacts(const DssWorld *W, void *stream);
 

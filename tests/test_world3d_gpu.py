@@ -58,3 +58,21 @@ def test_batchworld3d_parameter_gradients_flow():
     (w.pose[:, :, 4:] ** 2).sum().backward()
     gr = prm.grad[:, 1, 0]
     assert torch.isfinite(gr).all() and (gr != 0).any()
+
+
+def test_engine_plugin_solve_dynamics_matches_the_step():
+    """B2: HipPdipmEngine.solve_dynamics(world, dt) (engines.py:31-83) returns the velocities the next accepted
+    sub-step integrates with, without advancing the world."""
+    from diffsdfsim_amd.physics3d import HipPdipmEngine
+    g = R.load_rollout("rollout_sphere_notoc")
+    w, floor, ball, rad = build_sphere_world(g, toc=False)
+    for _ in range(9):
+        w.step(fixed_dt=True)
+    p_before = w.pose.clone()
+    v_new = w.engine_plugin.solve_dynamics(w, w.dt)
+    assert isinstance(w.engine_plugin, HipPdipmEngine)
+    assert torch.equal(w.pose, p_before)
+    n0 = int(w.engine.get("nsub")[0])
+    w.step(fixed_dt=True)
+    if int(w.engine.get("nsub")[0]) == n0 + 1:      # accepted at the first attempt: same dt, same solve
+        assert torch.allclose(v_new.reshape(2, 6), w.vel[0], rtol=0, atol=1e-14)
