@@ -115,6 +115,7 @@ def main():
     run("rollout_sphere_notoc", lambda: scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0)), nsteps=24, toc=False)
     run("rollout_stack1", lambda: scenes.box_stack(nbox=1, seed=3, vel_scale=1.0, push=2.0), nsteps=4)
     run("rollout_stack2", lambda: scenes.box_stack(nbox=2, seed=4, vel_scale=0.5, push=1.5), nsteps=3)
+    run("rollout_boxdrop", lambda: scenes.box_drop(seed=7), nsteps=12)
 
 
 if __name__ == "__main__":

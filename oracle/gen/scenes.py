@@ -55,3 +55,25 @@ def sphere_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), rad=None, y0=None, vx=None, 
                      restitution=rest, fric_coeff=mu)
     ball.add_force(Gravity3D())
     return [floor, ball], [TotalConstraint3D(floor)], [rad_t]
+
+
+def box_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), height=0.25, mu=0.4, rest=0.3, requires_grad=True):
+    """A tilted box dropped onto the floor: impact inside a step => rejected attempts, dt halving, a time-of-contact
+    event and (after the bounce) sliding with friction."""
+    from sdf_physics.physics3d.bodies import SDFBox
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+
+    g = torch.Generator().manual_seed(seed)
+    floor = SDFBox([0, -floor_dims[1] / 2, 0], list(floor_dims), custom_mesh=True, custom_inertia=True,
+                   restitution=rest, fric_coeff=mu)
+    dims = 0.5 + 0.2 * torch.rand(3, generator=g, dtype=torch.double)
+    if requires_grad:
+        dims.requires_grad_()
+    ang = 0.3 * (torch.rand(3, generator=g, dtype=torch.double) - 0.5)
+    pos = torch.tensor([ang[0].item(), ang[1].item(), ang[2].item(), 0.0, height + 0.5 * dims.detach().max().item(), 0.0],
+                       dtype=torch.double)
+    vel = torch.tensor([0.2, -0.1, 0.3, 0.8, -0.5, 0.2], dtype=torch.double)
+    b = SDFBox(pos, dims, vel=vel, custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    b.add_force(Gravity3D())
+    return [floor, b], [TotalConstraint3D(floor)], [dims]
