@@ -1,0 +1,76 @@
+"""Config 1 (BASELINE.json configs[0]): the reference's own 2-D CPU case -- Circle bouncing on a Rect,
+lcp_physics.physics World + DiffContactHandler (analytic contacts), 50 steps fwd+bwd.
+
+The 2-D host logic (bodies, GJK contacts) is outside the hot path ("config 1 only");
+what config 1 exercises on the path is boundary B1.  This script records every LCPFunction call the
+reference makes during the rollout (operands, solution, multipliers, and the upstream gradient autograd
+feeds into its backward) -> tests/golden/config1_lcp.npz, plus the final state and d loss / d rad.
+Run in the build container only:  python -m oracle.gen.gen_config1_golden
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+import lcp_physics.lcp.solvers.batch as B  # noqa: E402
+import lcp_physics.physics.engines as engines  # noqa: E402
+from lcp_physics.physics.bodies import Circle, Rect  # noqa: E402
+from lcp_physics.physics.constraints import TotalConstraint  # noqa: E402
+from lcp_physics.physics.forces import Gravity  # noqa: E402
+from lcp_physics.physics.world import World  # noqa: E402
+
+
+def main():
+    rad = torch.tensor(20.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.5, fric_coeff=0.9)
+    ball = Circle([500, 480], rad, vel=[0, 30, 0], restitution=0.5, fric_coeff=0.9)
+    ball.add_force(Gravity(g=100))
+    calls = []
+    orig_fn, orig_fwd = engines.LCPFunction, B.forward
+    state = {}
+
+    def fwd(*a, **k):
+        out = orig_fwd(*a, **k)
+        state["xyzs"] = [None if o is None else o.clone() for o in out]
+        return out
+
+    def spy(**kw):
+        fn = orig_fn(**kw)
+
+        def call(*ops):
+            z = fn(*ops)
+            rec = {"kw": kw, "ops": [o.detach().clone() for o in ops], "z": z.detach().clone(),
+                   "lam": state["xyzs"][2], "slack": state["xyzs"][3], "nu": state["xyzs"][1]}
+            z.register_hook(lambda g, rec=rec: rec.__setitem__("dl", g.clone()))
+            calls.append(rec)
+            return z
+        return call
+
+    B.forward = fwd
+    w = World([floor, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+    w.engine.lcp_solver = spy
+    for _ in range(50):
+        w.step()
+    loss = (ball.pos ** 2).sum()
+    loss.backward()
+    B.forward = orig_fwd
+    d = {"n_calls": np.int64(len(calls)), "final_p": torch.cat([b.p for b in (floor, ball)]).detach().numpy(),
+         "loss": float(loss), "drad": rad.grad.numpy(), "t_final": float(w.t), "n_substeps": np.int64(len(w.trajectory))}
+    for i, c in enumerate(calls):
+        for n, o in zip("QpGhAbF", c["ops"]):
+            d["c%d_%s" % (i, n)] = o.numpy()
+        d["c%d_z" % i] = c["z"].numpy(); d["c%d_lam" % i] = c["lam"].numpy(); d["c%d_slack" % i] = c["slack"].numpy()
+        d["c%d_nu" % i] = c["nu"].numpy(); d["c%d_dl" % i] = c["dl"].numpy(); d["c%d_max_iter" % i] = np.int64(c["kw"]["max_iter"])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1_lcp.npz"), **d)
+    print("config 1: %d LCP calls in %d sub-steps, final p %s, dL/drad %.6f" % (len(calls), len(w.trajectory), d["final_p"], float(rad.grad)),
+          [tuple(c["ops"][2].shape) for c in calls][:5])
+
+
+if __name__ == "__main__":
+    main()

@@ -43,3 +43,14 @@ def random_lcp(seed, nB, nz, nineq, neq, with_F=True):
     Fh = r.standard_normal((nB, nineq, nineq)) * 0.1
     F = Fh @ Fh.transpose(0, 2, 1) + 0.05 * r.standard_normal((nB, nineq, nineq)) if with_F else np.zeros((nB, nineq, nineq))
     return Q, p, G, h, A, b, F
+
+
+def config1_calls():
+    """LCP calls recorded from the reference's 2-D config-1 rollout (oracle/gen/gen_config1_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, "config1_lcp.npz"))
+    out = []
+    for i in range(int(g["n_calls"])):
+        c = {k: g["c%d_%s" % (i, k)] for k in ("Q", "p", "G", "h", "A", "b", "F", "z", "lam", "slack", "nu", "dl")}
+        c["max_iter"] = int(g["c%d_max_iter" % i])
+        out.append(c)
+    return out

@@ -30,3 +30,10 @@ def test_emulated_kernel_matches_oracle_random():
     z, lam, s, nu, it, st = emu.lcp_dense_forward(Q, p, G, h, A, b, F)
     zo, lo, so, nuo, ito, sto = O.forward(Q, p, G, h, A, b, F)
     assert (it == ito).all() and rel(z, zo) < 1e-10
+
+
+def test_emulated_kernel_on_config1_calls():
+    from helpers import config1_calls
+    for c in config1_calls():
+        z, lam, s, nu, it, st = emu.lcp_dense_forward(c["Q"], c["p"], c["G"], c["h"], c["A"], c["b"], c["F"], max_iter=c["max_iter"])
+        assert rel(z, c["z"]) < 1e-10

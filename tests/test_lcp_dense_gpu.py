@@ -95,3 +95,19 @@ def test_non_spd_raises_like_reference():
     with pytest.raises(RuntimeError, match="Q is not SPD"):
         LCPFunction()(Q, torch.zeros(1, 4, device="cuda").double(), torch.ones(1, 2, 4, device="cuda").double(),
                       torch.ones(1, 2, device="cuda").double(), e, e, torch.zeros(1, 2, 2, device="cuda").double())
+
+
+def test_config1_reference_cpu_case_through_lcpfunction():
+    """BASELINE configs[0]: the LCP the reference's 2-D ball-on-plane rollout solves, through the drop-in
+    LCPFunction on the device, forward and backward (upstream gradient as recorded from torch.autograd)."""
+    from helpers import config1_calls
+    from diffsdfsim_amd.lcp import LCPFunction
+    from oracle import lcp_oracle as O
+    for c in config1_calls():
+        ops = [T(c[k]).requires_grad_() for k in "QpGhAbF"]
+        z = LCPFunction(max_iter=c["max_iter"], verbose=-1)(*ops)
+        assert rel(z.detach().cpu().numpy(), c["z"]) < 1e-10
+        z.backward(T(c["dl"]))
+        want = O.backward(c["Q"], c["G"], c["A"], c["F"], c["z"], c["lam"], c["slack"], c["nu"], c["dl"])
+        for t, w in zip(ops, want):
+            assert rel(t.grad.cpu().numpy(), w) < 1e-7

@@ -34,3 +34,11 @@ def test_oracle_flags_non_spd():
     z, lam, s, nu, it, st = O.forward(Q, np.zeros((1, 4)), np.ones((1, 2, 4)), np.ones((1, 2)), np.zeros((1, 0, 4)),
                                       np.zeros((1, 0)), np.zeros((1, 2, 2)))
     assert st[0] == 1
+
+
+def test_oracle_on_config1_calls():
+    """BASELINE configs[0] (2-D Circle on Rect, the reference's own CPU case): every LCP call of the rollout."""
+    from helpers import config1_calls
+    for c in config1_calls():
+        z, lam, s, nu, it, st = O.forward(c["Q"], c["p"], c["G"], c["h"], c["A"], c["b"], c["F"], max_iter=c["max_iter"])
+        assert rel(z, c["z"]) < 1e-10 and rel(lam, c["lam"]) < 1e-6
