@@ -231,11 +231,11 @@ template <class T> __host__ __device__ inline void world_inertia(const T *q, con
 }
 
 // ---- primitive SDFs (physics3d/bodies.py:38-95) and SDF3D.query_sdfs (:721-760) -------------
-enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1 };
+enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2 };
 
 template <class T> struct Shape {
     int type;
-    T prm[3];   // box: dims ; sphere: rad
+    T prm[3];   // box: dims ; sphere: rad ; cylinder: rad, height (axis = body z)
     T scale;    // box: 1.5*max(dims)/2 ; sphere: 1.5*rad   (bodies.py:782, 987)
     T hd[3];    // box: (dims/scale)/2 ; sphere: hd[0] = rad/scale   (hoisted: invariant per body)
 };
@@ -246,6 +246,9 @@ template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int t
     if (type == SHAPE_BOX) {
         s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
         for (int i = 0; i < 3; ++i) s.hd[i] = (prm[i] / s.scale) / 2.0;
+    } else if (type == SHAPE_CYLINDER) {   // bodies.py:913-921: scale = 1.5 max(rad, height/2), params rad/scale, height/scale
+        s.scale = t_max(prm[0], prm[1] / 2.0) * 1.5;
+        s.hd[0] = prm[0] / s.scale; s.hd[1] = (prm[1] / s.scale) / 2.0; s.hd[2] = T(0.0);
     } else {
         s.scale = prm[0] * 1.5;
         s.hd[0] = prm[0] / s.scale; s.hd[1] = T(0.0); s.hd[2] = T(0.0);
@@ -274,6 +277,26 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
             T g1[3];
             normalize(go, g1);
             normalize(g1, g);  // query_sdfs normalises again (bodies.py:748)
+        }
+    } else if (s.type == SHAPE_CYLINDER) {
+        // cylinder_sdf / cylinder_sdf_grad (bodies.py:85-124): a 2-D box SDF in (radial, axial) coordinates
+        const T rho = t_sqrt(p[0] * p[0] + p[1] * p[1]);
+        T q[2] = {t_abs(rho) - s.hd[0], t_abs(p[2]) - s.hd[1]};
+        const T md = t_max(q[0], q[1]);
+        T m[2] = {t_clamp_min(q[0], 0.0), t_clamp_min(q[1], 0.0)};
+        phi = t_sqrt(m[0] * m[0] + m[1] * m[1]) + t_clamp_max(md, 0.0);
+        if (want_grad) {
+            T nm = t_sqrt(m[0] * m[0] + m[1] * m[1]);
+            if (val(nm) < 1e-12) nm = T(1e-12);
+            const double inside = val(md) <= 0.0 ? 1.0 : 0.0;
+            const T g0 = m[0] / nm + inside * (val(q[0]) == val(md) ? 1.0 : 0.0);
+            const T g1 = m[1] / nm + inside * (val(q[1]) == val(md) ? 1.0 : 0.0);
+            const double sg = val(p[2]) < 0.0 ? -1.0 : 1.0;
+            T rxy = rho;                              // normalize(pts[:, :2])
+            if (val(rxy) < 1e-12) rxy = T(1e-12);
+            T go[3] = {g0 * (p[0] / rxy), g0 * (p[1] / rxy), g1 * sg}, g1n[3];
+            normalize(go, g1n);
+            normalize(g1n, g);  // query_sdfs normalises again (bodies.py:748)
         }
     } else {
         const T n = norm3(p);

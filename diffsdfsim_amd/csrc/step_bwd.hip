@@ -86,7 +86,8 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
             for (int i = 0; i < 3; ++i) {
                 const double val0 = W.verts[(size_t)(voff + fv[v]) * 3 + i], gr = W.vgrad[(size_t)(voff + fv[v]) * 3 + i];
                 D d(val0);
-                const int t = (ty1 == SHAPE_BOX) ? 14 + i : 14, s = t - N * grp;  // box: own axis; sphere: radius
+                // box: own axis; sphere: radius; cylinder: x,y <- rad, z <- height
+                const int t = (ty1 == SHAPE_BOX) ? 14 + i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 15 : 14), s = t - N * grp;
                 if (s >= 0 && s < N) d.d[s] = gr;
                 tri[v][i] = d;
             }

@@ -63,6 +63,12 @@ def default_vgrad(shape_type, prm, verts):
     if shape_type == abi.SHAPE_BOX:
         hd = np.asarray(prm, np.float64)[:3] / 2
         return np.where(np.abs(verts) == hd[None, :], 0.5 * np.sign(verts), 0.0)
+    if shape_type == abi.SHAPE_CYLINDER:
+        rho = np.maximum(np.hypot(verts[:, 0], verts[:, 1]), 1e-300)
+        hh = float(prm[1]) / 2
+        side = rho > 0.5 * float(prm[0])
+        return np.stack([np.where(side, verts[:, 0] / rho, 0.0), np.where(side, verts[:, 1] / rho, 0.0),
+                         np.where(verts[:, 2] == hh, 0.5, np.where(verts[:, 2] == -hh, -0.5, 0.0))], axis=1)
     return verts / float(prm[0])
 
 

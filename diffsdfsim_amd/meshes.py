@@ -133,3 +133,32 @@ def icosphere(subdivisions=4):
 def sphere_mesh(rad, subdivisions=4):
     v, f = icosphere(subdivisions)
     return v * float(rad), f
+
+
+def cylinder_mesh(rad, height, numsegs=32, max_tri_length=0.1):
+    """Side rings + two fans (layout of `bodies.py:939-976`); axis = z.  Returns verts, faces and the vertex
+    gradient rows (d v_x/d rad, d v_y/d rad, d v_z/d height): the side coordinates scale with rad, only the end
+    rings and the two cap centres are tied to +-height/2."""
+    rad, height = float(rad), float(height)
+    thetas = _linspace(0.0, 2 * math.pi * (numsegs - 1) / numsegs, numsegs)
+    hh = height / 2
+    nv = int(math.ceil(height / max_tri_length)) + 1
+    zs = _linspace(-hh, hh, nv)
+    zs[0], zs[-1] = -hh, hh
+    T, Z = np.meshgrid(thetas, zs, indexing="ij")
+    side = np.stack([rad * np.cos(T), rad * np.sin(T), Z], axis=0).reshape(3, -1).T
+    verts = np.concatenate([side, [[0.0, 0.0, hh], [0.0, 0.0, -hh]]])
+    inds = np.arange(numsegs * nv).reshape(numsegs, nv)
+    inds = np.concatenate([inds, inds[:1]], axis=0)
+    faces = np.concatenate([
+        np.stack([inds[:-1, :-1], inds[1:, 1:], inds[:-1, 1:]], axis=2).reshape(-1, 3),
+        np.stack([inds[:-1, :-1], inds[1:, :-1], inds[1:, 1:]], axis=2).reshape(-1, 3)])
+    V = len(verts)
+    top = np.stack([np.full(numsegs, V - 2), inds[:-1, -1], inds[1:, -1]], axis=1)
+    bot = np.stack([np.full(numsegs, V - 1), inds[1:, 0], inds[:-1, 0]], axis=1)
+    faces = np.concatenate([faces, top, bot]).astype(np.int64)
+    vgrad = np.zeros_like(verts)
+    vgrad[:len(side), 0] = np.cos(T).reshape(-1)
+    vgrad[:len(side), 1] = np.sin(T).reshape(-1)
+    vgrad[:, 2] = np.where(verts[:, 2] == hh, 0.5, np.where(verts[:, 2] == -hh, -0.5, 0.0))
+    return verts, faces, vgrad

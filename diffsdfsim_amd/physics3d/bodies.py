@@ -109,3 +109,28 @@ class SDFSphere(Body3D):
 
     def _get_ang_inertia(self, mass):   # bodies.py:993-994
         return 2.0 / 5.0 * mass * self.rad ** 2 * torch.eye(3, dtype=torch.float64)
+
+
+class SDFCylinder(Body3D):
+    """`sdf_physics/physics3d/bodies.py:907-976`: cylinder along the body z axis (custom mesh / inertia)."""
+    shape_type = abi.SHAPE_CYLINDER
+
+    def __init__(self, pos, rad, height, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
+                 custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
+        if not (custom_mesh and custom_inertia):
+            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1)")
+        self.rad, self.height = get_tensor(rad), get_tensor(height)
+        self.scale = torch.max(self.rad, self.height / 2) * 1.5
+        self.verts_np, self.faces_np, self.vgrad_np = meshes.cylinder_mesh(float(self.rad.detach()), float(self.height.detach()))
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return torch.stack([self.rad.reshape(()), self.height.reshape(()), self.rad.new_zeros(())])
+
+    def _get_ang_inertia(self, mass):   # bodies.py:925-927
+        a = (3 * self.rad ** 2 + self.height ** 2) / 12
+        return mass * torch.diag(torch.stack([a, a, self.rad ** 2 / 2]))

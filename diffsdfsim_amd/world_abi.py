@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 CAND_FIELDS = 28
-SHAPE_BOX, SHAPE_SPHERE = 0, 1
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
 
 _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 

@@ -122,7 +122,7 @@ typedef struct DssWorld {
     /* body parameters, [B][nb](...) */
     const double *mass, *inertia /*[9]*/, *restitution, *fric, *fext /*[6]*/;
     const int *shape_type;      /* DSS_SHAPE_* */
-    const double *shape_prm;    /* [3]: box dims | sphere radius */
+    const double *shape_prm;    /* [3]: box dims | sphere radius | cylinder rad, height */
     const int *mesh_id;
     const unsigned char *no_contact; /* [nb][nb], shared by all scenes */
     /* mesh table (body frame) */
@@ -131,7 +131,8 @@ typedef struct DssWorld {
     const int *faces;      /* [NF][3] vertex ids local to the mesh */
     const double *fcent;   /* [NF][3] face centroids, */
     const double *frad;    /* [NF]    max centroid-vertex distance (both pose invariant) */
-    const double *vgrad;   /* [NV][3] d vertex / d shape parameter: box d v_k/d dims_k ; sphere d v/d rad */
+    const double *vgrad;   /* [NV][3] d vertex / d shape parameter: box d v_k/d dims_k ; sphere d v/d rad ;
+                              cylinder (d v_x/d rad, d v_y/d rad, d v_z/d height) */
     /* culling boxes (body frame) of every run of 256 consecutive faces / vertices of a mesh:
        [NCH][6] = lo(3), hi(3); face boxes bound centroid +- radius.  mesh_fch_off/mesh_vch_off [nmesh]. */
     const double *fch_box, *vch_box;
@@ -189,6 +190,7 @@ typedef struct DssWorld {
 #define DSS_CSCR_ROWS 56
 #define DSS_SHAPE_BOX 0
 #define DSS_SHAPE_SPHERE 1
+#define DSS_SHAPE_CYLINDER 2   /* shape_prm = (rad, height, -), axis = body z */
 
 size_t dss_world_sizeof(void);   /* sizeof(DssWorld): lets a binding check its mirror struct */
 

@@ -19,7 +19,7 @@ from oracle import refshim  # noqa: E402
 refshim.install()
 from oracle.gen import scenes  # noqa: E402
 from sdf_physics.physics3d.world import World3D  # noqa: E402
-from sdf_physics.physics3d.bodies import SDFBox, SDFSphere  # noqa: E402
+from sdf_physics.physics3d.bodies import SDFBox, SDFCylinder, SDFSphere  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 MAXC = 160
@@ -38,11 +38,13 @@ def contacts_arrays(contacts):
 def describe(bodies, g=10.0):
     d = {}
     nb = len(bodies)
-    d["shape_type"] = np.array([0 if isinstance(b, SDFBox) else 1 for b in bodies], np.int32)
+    d["shape_type"] = np.array([0 if isinstance(b, SDFBox) else (2 if isinstance(b, SDFCylinder) else 1) for b in bodies], np.int32)
     prm = np.zeros((nb, 3))
     for i, b in enumerate(bodies):
         if isinstance(b, SDFBox):
             prm[i] = b.dims.detach().numpy()
+        elif isinstance(b, SDFCylinder):
+            prm[i, 0], prm[i, 1] = float(b.rad), float(b.height)
         else:
             prm[i, 0] = float(b.rad)
     d["shape_prm"] = prm
@@ -116,6 +118,7 @@ def main():
     run("rollout_stack1", lambda: scenes.box_stack(nbox=1, seed=3, vel_scale=1.0, push=2.0), nsteps=4)
     run("rollout_stack2", lambda: scenes.box_stack(nbox=2, seed=4, vel_scale=0.5, push=1.5), nsteps=3)
     run("rollout_boxdrop", lambda: scenes.box_drop(seed=7), nsteps=12)
+    run("rollout_cylinder", lambda: scenes.cylinder_drop(seed=9), nsteps=10)
 
 
 if __name__ == "__main__":

@@ -77,3 +77,21 @@ def box_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), height=0.25, mu=0.4, rest=0.3, 
     b = SDFBox(pos, dims, vel=vel, custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
     b.add_force(Gravity3D())
     return [floor, b], [TotalConstraint3D(floor)], [dims]
+
+
+def cylinder_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), mu=0.4, rest=0.3, requires_grad=True):
+    """A tilted cylinder dropped onto the floor (curved side + flat caps + rim contacts)."""
+    from sdf_physics.physics3d.bodies import SDFBox, SDFCylinder
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+
+    g = torch.Generator().manual_seed(seed)
+    floor = SDFBox([0, -floor_dims[1] / 2, 0], list(floor_dims), custom_mesh=True, custom_inertia=True,
+                   restitution=rest, fric_coeff=mu)
+    rad = torch.tensor(0.25 + 0.1 * torch.rand(1, generator=g, dtype=torch.double).item(), dtype=torch.double, requires_grad=requires_grad)
+    height = torch.tensor(0.6 + 0.2 * torch.rand(1, generator=g, dtype=torch.double).item(), dtype=torch.double, requires_grad=requires_grad)
+    pos = torch.tensor([1.2, 0.3, 0.1, 0.0, 0.55, 0.0], dtype=torch.double)   # tipped by ~70 degrees about x
+    vel = torch.tensor([0.0, 0.2, 0.5, 0.4, -0.3, 0.1], dtype=torch.double)
+    c = SDFCylinder(pos, rad, height, vel=vel, custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    c.add_force(Gravity3D())
+    return [floor, c], [TotalConstraint3D(floor)], [rad, height]

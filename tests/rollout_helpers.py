@@ -66,6 +66,11 @@ def param_grads(E, g, s=0):
             # custom box inertia m/12 diag(d1^2+d2^2, d0^2+d2^2, d0^2+d1^2) (bodies.py:796-797)
             dI = np.array([(gI[1, 1] + gI[2, 2]) * 2 * d[0], (gI[0, 0] + gI[2, 2]) * 2 * d[1], (gI[0, 0] + gI[1, 1]) * 2 * d[2]]) * m / 12
             out.append(adj["g_prm"][s, b] + dI)
+        elif g["shape_type"][b] == 2:
+            r, h = g["shape_prm"][b, 0], g["shape_prm"][b, 1]
+            # custom cylinder inertia m diag(a, a, r^2/2), a = (3 r^2 + h^2)/12 (bodies.py:925-927)
+            out.append(np.array(adj["g_prm"][s, b, 0] + m * (0.5 * r * (gI[0, 0] + gI[1, 1]) + r * gI[2, 2])))
+            out.append(np.array(adj["g_prm"][s, b, 1] + m * h / 6 * (gI[0, 0] + gI[1, 1])))
         else:
             r = g["shape_prm"][b, 0]
             out.append(np.array(adj["g_prm"][s, b, 0] + 0.8 * m * r * np.trace(gI)))  # 2/5 m r^2 I (bodies.py:993-994)

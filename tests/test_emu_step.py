@@ -15,7 +15,7 @@ def test_initial_contacts_match_reference(name):
     R.check_contacts(E, 0, g["init_body"], g["init_geom"], len(g["init_body"]))
 
 
-@pytest.mark.parametrize("name,nsteps", [("rollout_sphere", 24), ("rollout_stack1", 2), ("rollout_boxdrop", 12)])
+@pytest.mark.parametrize("name,nsteps", [("rollout_sphere", 24), ("rollout_stack1", 2), ("rollout_boxdrop", 12), ("rollout_cylinder", 10)])
 def test_rollout_matches_reference(name, nsteps):
     g = R.load_rollout(name)
     E = BatchEngine(R.spec_from_golden(g), backend=emu.EmuBackend(), max_sub=64, **R.engine_kwargs(g))

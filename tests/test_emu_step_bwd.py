@@ -8,7 +8,7 @@ from emu import emu
 from diffsdfsim_amd.engine import BatchEngine
 
 
-@pytest.mark.parametrize("name,nsteps", [("rollout_sphere_notoc", 24), ("rollout_sphere", 24), ("rollout_stack1", 4), ("rollout_stack2", 3), ("rollout_boxdrop", 12)])
+@pytest.mark.parametrize("name,nsteps", [("rollout_sphere_notoc", 24), ("rollout_sphere", 24), ("rollout_stack1", 4), ("rollout_stack2", 3), ("rollout_boxdrop", 12), ("rollout_cylinder", 10)])
 def test_gradients_match_reference_autograd(name, nsteps):
     g = R.load_rollout(name)
     E = BatchEngine(R.spec_from_golden(g), backend=emu.EmuBackend(), max_sub=64, **R.engine_kwargs(g))

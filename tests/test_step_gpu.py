@@ -25,7 +25,7 @@ def test_initial_contacts_match_reference(name):
         R.check_contacts(E, s, g["init_body"], g["init_geom"], len(g["init_body"]))
 
 
-@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere", 24, 5), ("rollout_stack1", 4, 4), ("rollout_stack2", 3, 130), ("rollout_boxdrop", 12, 3)])
+@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere", 24, 5), ("rollout_stack1", 4, 4), ("rollout_stack2", 3, 130), ("rollout_boxdrop", 12, 3), ("rollout_cylinder", 10, 3)])
 def test_rollout_matches_reference(name, nsteps, copies):
     g, E = make(name, copies, max_sub=64)
     for _ in range(nsteps):
@@ -46,7 +46,7 @@ def test_rollout_matches_reference(name, nsteps, copies):
         assert np.abs(tp[j, 0] - g["traj_p"][j - 1]).max() < 1e-8
 
 
-@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere_notoc", 24, 3), ("rollout_sphere", 24, 3), ("rollout_stack1", 4, 2), ("rollout_stack2", 3, 65), ("rollout_boxdrop", 12, 2)])
+@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere_notoc", 24, 3), ("rollout_sphere", 24, 3), ("rollout_stack1", 4, 2), ("rollout_stack2", 3, 65), ("rollout_boxdrop", 12, 2), ("rollout_cylinder", 10, 2)])
 def test_gradients_match_reference_autograd(name, nsteps, copies):
     """Reverse sweep (csrc/step_bwd.hip) vs torch.autograd of the reference: d sum|pos_T|^2 / d(dims | radius).
     Flat-on-flat contacts make the reference gradient bimodal (both branches are in the golden)."""
