@@ -110,7 +110,7 @@ def main():
     # strict_no_pen=False as in the reference's own long-running experiments (optim_sysid.py:104-131): a scene
     # whose penetration cannot be resolved by halving dt proceeds once dt < dt/2^10 (world.py:345-347) instead of
     # retrying forever, which with strict=True stalls the reference as well.
-    E = BatchEngine(spec, maxc=192, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16,
+    E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16,
                     strict_no_pen=False, backend=TorchBackend(dev))
 
     def loss_adjoint():

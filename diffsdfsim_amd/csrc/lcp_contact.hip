@@ -165,13 +165,18 @@ struct Lds {
     int *bl_start;  // [nb+1]
     int *bl_ent;    // [2*maxc]  contact*2 + side
     int *cb;        // [2][maxc] body ids (LDS copy)
-    int n, lda, nz, neq, nb, maxc;
+    int n, kn, lda, nz, neq, nb, maxc;
+    double *kf;     // global: [n][64] factored rows parked between the solves of an iteration (register path)
+    const double *Ag;   // global equality rows [neq][nz]
 };
 
+// sizes with a register-resident factor/solve: only H = Q + sum P C P^T is assembled in LDS, the equality rows join
+// in registers and the factored rows are parked in the (L2-resident) workspace between the two solves of an iteration
+__host__ __device__ inline bool reg_path(int n) { return n == 54 || n == 18; }
 __host__ __device__ inline size_t lds_doubles(int nb, int neq, int maxc)
 {
-    const int nz = 6 * nb, n = nz + neq, lda = n | 1;
-    return (size_t)n * lda + 6 * (size_t)maxc + 9 * (size_t)maxc + 3 * (size_t)n + 3 * (size_t)nz + 4;
+    const int nz = 6 * nb, n = nz + neq, kn = reg_path(n) ? nz : n, lda = kn | 1;
+    return (size_t)kn * lda + 6 * (size_t)maxc + 9 * (size_t)maxc + 3 * (size_t)n + 3 * (size_t)nz + 4;
 }
 __host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
 {
@@ -180,9 +185,11 @@ __host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
 }
 __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc)
 {
-    L.nb = nb; L.neq = neq; L.maxc = maxc; L.nz = 6 * nb; L.n = L.nz + neq; L.lda = L.n | 1;
+    L.nb = nb; L.neq = neq; L.maxc = maxc; L.nz = 6 * nb; L.n = L.nz + neq;
+    L.kn = reg_path(L.n) ? L.nz : L.n;
+    L.lda = L.kn | 1;
     double *q = base;
-    L.K = q; q += (size_t)L.n * L.lda;
+    L.K = q; q += (size_t)L.kn * L.lda;
     L.pbuf = q; q += 6 * maxc;
     L.cw = q; q += 9 * maxc;
     L.xv = q; q += L.n;
@@ -263,18 +270,19 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
 {
     const int *cbody = L.cb;
     const int lane = lane_id(), n = L.n, lda = L.lda, nz = L.nz;
-    for (int e = lane; e < n * lda; e += WAVE) L.K[e] = 0.0;
+    for (int e = lane; e < L.kn * lda; e += WAVE) L.K[e] = 0.0;
     __syncthreads();
     for (int e = lane; e < L.nb * 36; e += WAVE) {
         const int b = e / 36, i = (e % 36) / 6, j = e % 6;
         L.K[(6 * b + i) * lda + 6 * b + j] = Mblk[e];
     }
-    for (int e = lane; e < L.neq * nz; e += WAVE) {
-        const int i = e / nz, j = e % nz;
-        const double v = A[e];
-        L.K[(nz + i) * lda + j] = v;
-        L.K[j * lda + nz + i] = v;
-    }
+    if (L.kn == n)   // LDS fallback path keeps the whole KKT matrix
+        for (int e = lane; e < L.neq * nz; e += WAVE) {
+            const int i = e / nz, j = e % nz;
+            const double v = A[e];
+            L.K[(nz + i) * lda + j] = v;
+            L.K[j * lda + nz + i] = v;
+        }
     __syncthreads();
     // lanes 0..47: (row r of the 12 local rows) x (4 column groups of 3)
     const int r = lane >> 2, grp = lane & 3;
@@ -376,18 +384,33 @@ __device__ double solve_K(const Lds &L, double x)
 template <int N> __device__ double kkt_factor_solve_reg(Lds &L, double rhs)
 {
     RegK<N> R;
-    regk_load<N>(R, L.K, L.lda);
+    const int lane = lane_id(), nz = L.nz;
+    // row `lane` of K = [[H, A^T],[A, 0]]: H from LDS, equality rows straight from global
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double v = 0.0;
+        if (lane < nz) v = (j < nz) ? L.K[lane * L.lda + j] : L.Ag[(j - nz) * nz + lane];
+        else if (lane < N) v = (j < nz) ? L.Ag[(lane - nz) * nz + j] : 0.0;
+        R.a[j] = v;
+    }
+    R.step = N;
     regk_factor<N>(R);
     const double x = regk_solve<N>(R, rhs);
-    __syncthreads();
-    regk_store<N>(R, L.K, L.lda, L.piv);
+    if (L.kf) {   // the forward pass solves a second time with the same factors (corrector)
+#pragma unroll
+        for (int j = 0; j < N; ++j) L.kf[(size_t)j * WAVE + lane] = R.a[j];
+        if (lane < N) L.piv[lane] = R.step;
+    }
     __syncthreads();
     return x;
 }
 template <int N> __device__ double kkt_solve_reg(Lds &L, double rhs)
 {
     RegK<N> R;
-    regk_reload<N>(R, L.K, L.lda, L.piv);
+    const int lane = lane_id();
+#pragma unroll
+    for (int j = 0; j < N; ++j) R.a[j] = L.kf[(size_t)j * WAVE + lane];
+    R.step = lane < N ? L.piv[lane] : -1;
     return regk_solve<N>(R, rhs);
 }
 __device__ double kkt_factor_solve(Lds &L, double rhs)
@@ -453,7 +476,9 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
     const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
     double *x_out = x_out_ + (size_t)sc * nz, *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
     double *nu = neq ? nu_ + (size_t)sc * neq : nullptr;
-    double *ws = ws_ + (size_t)sc * 5 * NR * maxc;
+    double *ws = ws_ + (size_t)sc * (5 * NR * maxc + 64 * 64);
+    L.kf = ws + (size_t)5 * NR * maxc;
+    L.Ag = A;
     double *cs = ws, *cz = ws + (size_t)NR * maxc, *crz = ws + (size_t)2 * NR * maxc, *cds = ws + (size_t)3 * NR * maxc,
            *cdz = ws + (size_t)4 * NR * maxc;
     int nc = ncs[sc];
@@ -755,6 +780,8 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
     const int nz = L.nz, n = L.n;
     const double *Mblk = Mblk_ + (size_t)sc * nb * 36;
     const double *A = neq ? A_ + (size_t)sc * neq * nz : nullptr;
+    L.kf = nullptr;
+    L.Ag = A;
     const double *cop = cop_ + (size_t)sc * NF * maxc;
     const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
     const double *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
@@ -873,7 +900,7 @@ extern "C" {
 size_t dss_lcp_contact_workspace_bytes(int B, int nb, int neq, int maxc, int fric_dirs)
 {
     if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return 0;
-    return (size_t)B * 5 * (fric_dirs + 2) * maxc * sizeof(double);
+    return (size_t)B * (5 * (fric_dirs + 2) * maxc + 64 * 64) * sizeof(double);
 }
 
 int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double *A, const double *bvec,
