@@ -183,46 +183,41 @@ __device__ inline int compact_slot(int flag, int &count, Scratch &S)
     return flag ? off + pre : -1;
 }
 
-// block reductions: shuffles inside each wavefront, one LDS word per wavefront, two barriers
 // block arg-min over (key, index) with lowest index on ties; returns the index (or -1 if none valid)
 __device__ inline int block_argmin(double key, int idx, Scratch &S)
 {
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ok = __shfl_xor(key, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (oi >= 0 && (idx < 0 || ok < key || (ok == key && oi < idx))) { key = ok; idx = oi; }
-    }
-    if ((tid & 63) == 0) { S.red_d[tid >> 6] = key; S.red_i[tid >> 6] = idx; }
+    S.red_d[tid] = key; S.red_i[tid] = idx;
     __syncthreads();
-    double bk = S.red_d[0]; int bi = S.red_i[0];
-    for (int w = 1; w < NT / 64; ++w) {
-        const double ok = S.red_d[w]; const int oi = S.red_i[w];
-        if (oi >= 0 && (bi < 0 || ok < bk || (ok == bk && oi < bi))) { bk = ok; bi = oi; }
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ok = S.red_d[tid + s]; const int oi = S.red_i[tid + s];
+            const int mi = S.red_i[tid];
+            if (oi >= 0 && (mi < 0 || ok < S.red_d[tid] || (ok == S.red_d[tid] && oi < mi))) { S.red_d[tid] = ok; S.red_i[tid] = oi; }
+        }
+        __syncthreads();
     }
+    const int r = S.red_i[0];
     __syncthreads();
-    return bi;
+    return r;
 }
 __device__ inline double block_max(double v, Scratch &S)
 {
     const int tid = threadIdx.x;
-    v = wave_max(v);
-    if ((tid & 63) == 0) S.red_d[tid >> 6] = v;
+    S.red_d[tid] = v;
     __syncthreads();
-    double r = S.red_d[0];
-    for (int w = 1; w < NT / 64; ++w) r = fmax(r, S.red_d[w]);
+    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] = fmax(S.red_d[tid], S.red_d[tid + s]); __syncthreads(); }
+    const double r = S.red_d[0];
     __syncthreads();
     return r;
 }
 __device__ inline double block_sum(double v, Scratch &S)
 {
     const int tid = threadIdx.x;
-    v = wave_sum(v);
-    if ((tid & 63) == 0) S.red_d[tid >> 6] = v;
+    S.red_d[tid] = v;
     __syncthreads();
-    double r = S.red_d[0];
-    for (int w = 1; w < NT / 64; ++w) r += S.red_d[w];
+    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] += S.red_d[tid + s]; __syncthreads(); }
+    const double r = S.red_d[0];
     __syncthreads();
     return r;
 }
@@ -372,27 +367,23 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                 const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
                 if (cr < -1e-9 * sqrt(lb * lq) || (fabs(cr) <= 1e-9 * sqrt(lb * lq) && lq > lb)) { best = k; bx = qx; by = qy; }
             }
-            auto better = [&](int a, int b) {   // is candidate b preferable to a (both may be -1)
-                if (b < 0) return false;
-                if (a < 0) return true;
-                const double ax = S.hp[3 * a + c0] - cx, ay = S.hp[3 * a + c1] - cy;
-                const double qx = S.hp[3 * b + c0] - cx, qy = S.hp[3 * b + c1] - cy;
-                const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
-                return cr < -1e-9 * sqrt(la * lq) || (fabs(cr) <= 1e-9 * sqrt(la * lq) && (lq > la || (lq == la && b < a)));
-            };
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ob = __shfl_xor(best, o, 64);
-                if (better(best, ob)) best = ob;
-            }
-            if ((tid & 63) == 0) S.red_i[tid >> 6] = best;
+            S.red_i[tid] = best;
             __syncthreads();
-            if (tid == 0) {
-                int bb = S.red_i[0];
-                for (int w = 1; w < NT / 64; ++w) if (better(bb, S.red_i[w])) bb = S.red_i[w];
-                S.red_i[0] = bb;
+            for (int s = NT / 2; s > 0; s >>= 1) {
+                if (tid < s) {
+                    const int a = S.red_i[tid], b = S.red_i[tid + s];
+                    if (b >= 0) {
+                        if (a < 0) S.red_i[tid] = b;
+                        else {
+                            const double ax = S.hp[3 * a + c0] - cx, ay = S.hp[3 * a + c1] - cy;
+                            const double qx = S.hp[3 * b + c0] - cx, qy = S.hp[3 * b + c1] - cy;
+                            const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
+                            if (cr < -1e-9 * sqrt(la * lq) || (fabs(cr) <= 1e-9 * sqrt(la * lq) && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
             const int nxt = S.red_i[0];
             const int seen = nxt >= 0 ? (S.hflag[nxt] == 1) : 0;
             __syncthreads();   // every thread has read red_i / hflag before thread 0 flags the next vertex
