@@ -1,0 +1,47 @@
+"""IGR neural SDF on the fp64 matrix cores (C ABI: dss_igr_query, csrc/igr_mlp.hip).
+
+``pack_weights`` turns the nine Linear layers of the reference's ImplicitNet (PyTorch layout weight[out, in]) into
+the operand set of the kernel: layer 0 and layer 8 stay dense, the seven 128x128 layers go into MFMA fragment order
+``[tile t][k-step][lane] = W[16 t + (lane & 15)][4 ks + (lane >> 4)]`` so a wavefront fetches each B fragment with
+one coalesced 512-byte load.  Layer 3 has 123 outputs (the skip concat appends the 5 inputs): its missing rows are
+zero.  Real IGR checkpoints (`utils.py:310-320`) are not available offline; any state_dict with the same shapes works.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+H = 128
+
+
+def pack_weights(Ws, bs, device="cuda"):
+    Ws = [np.asarray(w, np.float64) for w in Ws]
+    bs = [np.asarray(b, np.float64) for b in bs]
+    assert Ws[0].shape == (H, 5) and Ws[8].shape == (1, H) and Ws[3].shape == (H - 5, H)
+    packed = np.zeros((7, 8, 32, 64))
+    bh = np.zeros((7, H))
+    lane = np.arange(64)
+    for l in range(1, 8):
+        W = np.zeros((H, H)); W[: Ws[l].shape[0]] = Ws[l]
+        bh[l - 1, : len(bs[l])] = bs[l]
+        for t in range(8):
+            for ks in range(32):
+                packed[l - 1, t, ks] = W[16 * t + (lane & 15), 4 * ks + (lane >> 4)]
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+    return dict(W0=t(Ws[0]), b0=t(bs[0]), Wp=t(packed), bh=t(bh), W8=t(Ws[8][0]), b8=t(bs[8]))
+
+
+def igr_query(pts, latent, P):
+    """pts [n,3], latent [2] (float64, HIP device) -> sdf [n], d sdf / d xyz [n,3]."""
+    _lib.require_device(pts, latent)
+    L = _lib.lib()
+    n = pts.shape[0]
+    sdf = torch.empty(n, dtype=torch.float64, device=pts.device)
+    grad = torch.empty(n, 3, dtype=torch.float64, device=pts.device)
+    rc = L.dss_igr_query(_lib.ptr(pts.contiguous()), _lib.ptr(latent.contiguous()), _lib.ptr(P["W0"]), _lib.ptr(P["b0"]),
+                         _lib.ptr(P["Wp"]), _lib.ptr(P["bh"]), _lib.ptr(P["W8"]), _lib.ptr(P["b8"]), int(n), _lib.ptr(sdf),
+                         _lib.ptr(grad), _lib.stream_ptr(pts.device))
+    _lib.check(rc, "dss_igr_query")
+    return sdf, grad

@@ -236,6 +236,19 @@ typedef struct DssAdjoint {
 size_t dss_adjoint_sizeof(void);
 int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * IGR neural SDF  --  decode_igr + the autograd input gradient of SDF3D.query_sdfs
+ *     sdf_physics/physics3d/utils.py:330-350, sdf_physics/physics3d/bodies.py:730-745
+ * Network of IGR_data/train_configs/bob_spot_setup.conf:38-45 (5 -> 128 x3 -> 123, skip, 128 x4 -> 1,
+ * Softplus(beta=100)), float64, on the fp64 matrix cores.  pts [n][3] body-frame points (already divided by the
+ * body scale), latent [2]; W0 [128][5], b0 [128]; Wp = the seven 128x128 layers in MFMA fragment order
+ * (dss_igr_packed_doubles() doubles, see diffsdfsim_amd/igr.py: pack_weights; layer 3's five missing rows are
+ * zero), bh [7][128]; W8 [128], b8 [1].  Outputs sdf [n] and d sdf / d xyz [n][3] (not normalised).
+ * ------------------------------------------------------------------------------------ */
+size_t dss_igr_packed_doubles(void);
+int dss_igr_query(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
+                  const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

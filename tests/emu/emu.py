@@ -115,3 +115,20 @@ class EmuBackend:
 
     def read_int(self, t):
         return int(t.reshape(-1)[0])
+
+
+def igr_query(pts, latent, Ws, bs):
+    L = lib()
+    H = 128
+    packed = np.zeros((7, 8, 32, 64)); bh = np.zeros((7, H)); lane = np.arange(64)
+    for l in range(1, 8):
+        W = np.zeros((H, H)); W[: Ws[l].shape[0]] = Ws[l]; bh[l - 1, : len(bs[l])] = bs[l]
+        for t in range(8):
+            for ks in range(32):
+                packed[l - 1, t, ks] = W[16 * t + (lane & 15), 4 * ks + (lane >> 4)]
+    pts = _c(pts); n = len(pts)
+    sdf = np.zeros(n); grad = np.zeros((n, 3))
+    W0, b0, W8, b8, lat = _c(Ws[0]), _c(bs[0]), _c(Ws[8][0]), _c(bs[8]), _c(latent)
+    rc = L.dss_igr_query(_p(pts), _p(lat), _p(W0), _p(b0), _p(packed), _p(bh), _p(W8), _p(b8), n, _p(sdf), _p(grad), None)
+    assert rc == 0
+    return sdf, grad

@@ -179,6 +179,27 @@ inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
+// v_mfma_f64_16x16x4_f64 as documented for gfx950 (cdna_hip_programming.md section 3): lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives D[row = (l>>4) + 4 r][col = l&15] in register r.
+struct dss_emu_acc4 { double x, y, z, w; };
+template <class ACC> inline ACC dss_emu_mfma_f64_16x16x4(double a, double b, ACC c)
+{
+    dss_emu::State &s = dss_emu::st();
+    static std::vector<double> A(64), B(64);
+    const int l = s.cur & 63;
+    A[l] = a; B[l] = b;
+    dss_emu::yield();
+    double *cv = reinterpret_cast<double *>(&c);
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) + 4 * r, col = l & 15;
+        double acc = cv[r];
+        for (int k = 0; k < 4; ++k) acc += A[16 * k + row] * B[16 * k + col];
+        cv[r] = acc;
+    }
+    dss_emu::yield();
+    return c;
+}
+
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     dss_emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
 
