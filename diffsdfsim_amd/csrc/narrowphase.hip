@@ -863,7 +863,7 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
 {
     if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
-    hipMemsetAsync(W.n_pairs, 0, 2 * sizeof(int), stream);   // [0] list length, [1] work cursor
+    (void)hipMemsetAsync(W.n_pairs, 0, 2 * sizeof(int), stream);   // [0] list length, [1] work cursor
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
     // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
     static const int wgs_per_cu = getenv("DSS_NP_WGS_PER_CU") ? atoi(getenv("DSS_NP_WGS_PER_CU")) : DSS_NP_WAVES;

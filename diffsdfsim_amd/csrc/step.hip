@@ -237,19 +237,19 @@ int dss_step_attempt(const DssWorld *W, void *lcp_workspace, size_t lcp_workspac
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(assemble_kernel, dim3(W->B), dim3(64), 0, stream, *W);
-    if (W->ev_lcp_start) hipEventRecord((hipEvent_t)W->ev_lcp_start, stream);
+    if (W->ev_lcp_start) (void)hipEventRecord((hipEvent_t)W->ev_lcp_start, stream);
     rc = dss_lcp_contact_forward(W->Mblk, W->pvec, W->Je, W->b_eq, W->cop, W->cop_body, W->nc,
                                  W->active, W->B, W->nb, W->neq, W->maxc, W->fric_dirs, 1e-12, 3, W->lcp_max_iter,
                                  W->x, W->lam, W->slack, W->nu, W->lcp_iters, W->lcp_status, lcp_workspace,
                                  lcp_workspace_bytes, stream_);
-    if (W->ev_lcp_stop) hipEventRecord((hipEvent_t)W->ev_lcp_stop, stream);
+    if (W->ev_lcp_stop) (void)hipEventRecord((hipEvent_t)W->ev_lcp_stop, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(integrate_kernel, dim3(W->B), dim3(64), 0, stream, *W);
     NewContacts N;
     N.nc = W->n_nc; N.body = W->n_body; N.face = W->n_face; N.abc = W->n_abc; N.geom = W->n_geom;
-    if (W->ev_np_start) hipEventRecord((hipEvent_t)W->ev_np_start, stream);
+    if (W->ev_np_start) (void)hipEventRecord((hipEvent_t)W->ev_np_start, stream);
     rc = dss::launch_find_contacts(*W, N.nc, N.body, N.face, N.abc, N.geom, stream);
-    if (W->ev_np_stop) hipEventRecord((hipEvent_t)W->ev_np_stop, stream);
+    if (W->ev_np_stop) (void)hipEventRecord((hipEvent_t)W->ev_np_stop, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(decide_kernel, dim3(W->B), dim3(64), 0, stream, *W, N);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;

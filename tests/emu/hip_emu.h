@@ -185,8 +185,9 @@ struct dss_emu_acc4 { double x, y, z, w; };
 template <class ACC> inline ACC dss_emu_mfma_f64_16x16x4(double a, double b, ACC c)
 {
     dss_emu::State &s = dss_emu::st();
-    static std::vector<double> A(64), B(64);
+    static std::vector<double> Aall(1024), Ball(1024);   // one 64-entry slab per wavefront of the block
     const int l = s.cur & 63;
+    double *A = Aall.data() + (s.cur & ~63), *B = Ball.data() + (s.cur & ~63);
     A[l] = a; B[l] = b;
     dss_emu::yield();
     double *cv = reinterpret_cast<double *>(&c);
