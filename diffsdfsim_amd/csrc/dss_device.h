@@ -5,7 +5,17 @@
 #pragma once
 #if defined(DSS_EMU)
 #include "hip_emu.h"
+// lanes of one emulated wavefront meet at every switch point
+inline void dss_wave_sync() { dss_emu::yield(); }
 #else
 #include <hip/hip_runtime.h>
 #define DSS_DYN_LDS(type, name) extern __shared__ __align__(16) type name[]
+// LDS written by one lane is visible to the other lanes of the SAME wavefront afterwards (no s_barrier: the LDS
+// queue of a wavefront is in order; the fence only stops the compiler from moving accesses across)
+__device__ __forceinline__ void dss_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #endif

@@ -30,6 +30,7 @@ using namespace dss;
 constexpr int NT = 256;
 constexpr int MAX_CPT = 8;       // candidates per thread: max_cand <= NT * MAX_CPT
 constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
+constexpr int WAVE_ITEM_MAX_FACES = 16 * 256;   // items that search a bigger mesh take a whole workgroup (WaveGroup::CHCAP runs)
 
 __device__ inline int npairs_of(int nb) { return nb * (nb - 1); }
 __device__ inline void pair_of(int dp, int nb, int &a, int &b)
@@ -144,9 +145,12 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
     if (tid == 0) {
         *flag = ok;
         if (ok) {
-            const int at = atomicAdd(W.n_pairs, 2);
-            W.pair_list[at] = sc * np + dp_ij;
-            W.pair_list[at + 1] = sc * np + dp_ji;
+            // list 0: items a whole workgroup works on (big mesh searched), list 1: one wavefront each
+            const int cap = W.B * np;
+            const int li = W.mesh_nf[W.mesh_id[(size_t)sc * W.nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
+            const int lj = W.mesh_nf[W.mesh_id[(size_t)sc * W.nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
+            W.pair_list[(size_t)li * cap + atomicAdd(W.n_pairs + 2 * li, 1)] = sc * np + dp_ij;
+            W.pair_list[(size_t)lj * cap + atomicAdd(W.n_pairs + 2 * lj, 1)] = sc * np + dp_ji;
         } else {
             W.pc_count[(size_t)sc * np + dp_ij] = 0;
             W.pc_count[(size_t)sc * np + dp_ji] = 0;
@@ -155,98 +159,112 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
 }
 
 // ---- workgroup scratch ------------------------------------------------------------------------
-constexpr int MAX_CH = 704;     // runs of 256 faces handled by the barrier-free scan (176 k-face floor = 688)
+// A work item (scene, directed pair a->b) is processed by a GROUP of threads: a whole 256-thread workgroup when
+// a's mesh is big (the 176 k-face floor), a single wavefront otherwise.  Most of the item is a serial chain
+// (Frank-Wolfe iterations of a handful of movers, greedy clustering, gift wrapping), so four independent
+// wavefronts per workgroup keep four times as many chains in flight; the wave flavour needs no s_barrier at all.
+//   BT    threads of the group             HCAP  capacity of the mover list / of one normal cluster
+//   CHCAP runs of 256 faces the barrier-free scan can hold (176 k-face floor = 688 runs)
+template <int BT_, int HCAP_, int CHCAP_> struct Group {
+    static constexpr int BT = BT_, HCAP = HCAP_, CHCAP = CHCAP_, NW = BT_ / 64;
+    __device__ static inline int tid() { return BT_ == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+    __device__ static inline void sync() { if (BT_ == 64) dss_wave_sync(); else __syncthreads(); }
+    __device__ static inline int any(int x) { if (BT_ == 64) return __ballot(x) != 0ull; else return __syncthreads_or(x); }
+};
+using BlockGroup = Group<256, 1024, 704>;
+using WaveGroup = Group<64, 384, 16>;
 
-struct Scratch {
-    int wave_tot[NT / 64];
-    int woff[MAX_CH * 4];
-    int vote[2][NT / 64];
-    int red_i[NT];
-    double red_d[NT];
-    double hp[3 * 1024];   // cluster points for the hull
-    int hidx[1024];
-    unsigned char hflag[1024];
+template <class G> struct ScratchT {
+    int wave_tot[G::NW];
+    int woff[G::CHCAP * 4];
+    int vote[2][G::NW];
+    int red_i[G::BT];
+    double red_d[G::BT];
+    double hp[3 * G::HCAP];   // cluster points for the hull
+    int hidx[G::HCAP];
+    unsigned char hflag[G::HCAP];
 };
 
 // ordered compaction: returns this thread's output slot (or -1) and updates the running count
-__device__ inline int compact_slot(int flag, int &count, Scratch &S)
+template <class G> __device__ inline int compact_slot(int flag, int &count, ScratchT<G> &S)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = G::tid(), lane = tid & 63, wv = tid >> 6;
     const unsigned long long m = __ballot(flag);
     const int pre = __popcll(m & ((1ull << lane) - 1ull)), tot = __popcll(m);
+    if (G::BT == 64) { const int off1 = count; count += tot; return flag ? off1 + pre : -1; }
     if (lane == 0) S.wave_tot[wv] = tot;
-    __syncthreads();
+    G::sync();
     int off = count, all = 0;
-    for (int w = 0; w < NT / 64; ++w) { if (w < wv) off += S.wave_tot[w]; all += S.wave_tot[w]; }
-    __syncthreads();
+    for (int w = 0; w < G::BT / 64; ++w) { if (w < wv) off += S.wave_tot[w]; all += S.wave_tot[w]; }
+    G::sync();
     count += all;
     return flag ? off + pre : -1;
 }
 
 // block arg-min over (key, index) with lowest index on ties; returns the index (or -1 if none valid)
-__device__ inline int block_argmin(double key, int idx, Scratch &S)
+template <class G> __device__ inline int block_argmin(double key, int idx, ScratchT<G> &S)
 {
-    const int tid = threadIdx.x;
+    const int tid = G::tid();
     S.red_d[tid] = key; S.red_i[tid] = idx;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
+    G::sync();
+    for (int s = G::BT / 2; s > 0; s >>= 1) {
         if (tid < s) {
             const double ok = S.red_d[tid + s]; const int oi = S.red_i[tid + s];
             const int mi = S.red_i[tid];
             if (oi >= 0 && (mi < 0 || ok < S.red_d[tid] || (ok == S.red_d[tid] && oi < mi))) { S.red_d[tid] = ok; S.red_i[tid] = oi; }
         }
-        __syncthreads();
+        G::sync();
     }
     const int r = S.red_i[0];
-    __syncthreads();
+    G::sync();
     return r;
 }
-__device__ inline double block_max(double v, Scratch &S)
+template <class G> __device__ inline double block_max(double v, ScratchT<G> &S)
 {
-    const int tid = threadIdx.x;
+    const int tid = G::tid();
     S.red_d[tid] = v;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] = fmax(S.red_d[tid], S.red_d[tid + s]); __syncthreads(); }
+    G::sync();
+    for (int s = G::BT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] = fmax(S.red_d[tid], S.red_d[tid + s]); G::sync(); }
     const double r = S.red_d[0];
-    __syncthreads();
+    G::sync();
     return r;
 }
-__device__ inline double block_sum(double v, Scratch &S)
+template <class G> __device__ inline double block_sum(double v, ScratchT<G> &S)
 {
-    const int tid = threadIdx.x;
+    const int tid = G::tid();
     S.red_d[tid] = v;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] += S.red_d[tid + s]; __syncthreads(); }
+    G::sync();
+    for (int s = G::BT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] += S.red_d[tid + s]; G::sync(); }
     const double r = S.red_d[0];
-    __syncthreads();
+    G::sync();
     return r;
 }
 
 // ---- hull of one normal cluster (points in S.hp, m of them); marks S.hflag ---------------------
 // Mirrors the fall-back ladder of contacts.py:126-152: 3-D hull; if Qhull would reject the input as
 // flat drop the coordinate of least variance and retry in 2-D; then 1-D min/max.
-__device__ void cluster_hull(Scratch &S, int m, double eps)
+template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double eps)
 {
-    const int tid = threadIdx.x;
-    for (int k = tid; k < m; k += NT) S.hflag[k] = 0;
-    __syncthreads();
-    if (m == 1) { if (tid == 0) S.hflag[0] = 1; __syncthreads(); return; }
+    const int tid = G::tid();
+    for (int k = tid; k < m; k += G::BT) S.hflag[k] = 0;
+    G::sync();
+    if (m == 1) { if (tid == 0) S.hflag[0] = 1; G::sync(); return; }
     // per-coordinate mean / unbiased variance (torch.var)
     double mean[3], var[3], amax = 0.0;
     for (int d = 0; d < 3; ++d) {
         double acc = 0.0, mx = 0.0;
-        for (int k = tid; k < m; k += NT) { acc += S.hp[3 * k + d]; mx = fmax(mx, fabs(S.hp[3 * k + d])); }
+        for (int k = tid; k < m; k += G::BT) { acc += S.hp[3 * k + d]; mx = fmax(mx, fabs(S.hp[3 * k + d])); }
         mean[d] = block_sum(acc, S) / m;
         amax = fmax(amax, block_max(mx, S));
         acc = 0.0;
-        for (int k = tid; k < m; k += NT) { const double t = S.hp[3 * k + d] - mean[d]; acc += t * t; }
+        for (int k = tid; k < m; k += G::BT) { const double t = S.hp[3 * k + d] - mean[d]; acc += t * t; }
         var[d] = block_sum(acc, S) / (m - 1);
     }
     const double tolf = 1e-12 * (1.0 + amax);
     // farthest point B from A = point 0, then C farthest from line AB
     const double *A = S.hp;
     double key = -1.0; int ki = -1;
-    for (int k = tid; k < m; k += NT) {
+    for (int k = tid; k < m; k += G::BT) {
         const double d0 = S.hp[3 * k] - A[0], d1 = S.hp[3 * k + 1] - A[1], d2 = S.hp[3 * k + 2] - A[2];
         const double dd = d0 * d0 + d1 * d1 + d2 * d2;
         if (dd > key) { key = dd; ki = k; }
@@ -258,7 +276,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
     double nrm[3] = {0, 0, 0};
     if (!line) {
         key = -1.0; ki = -1;
-        for (int k = tid; k < m; k += NT) {
+        for (int k = tid; k < m; k += G::BT) {
             const double d[3] = {S.hp[3 * k] - A[0], S.hp[3 * k + 1] - A[1], S.hp[3 * k + 2] - A[2]};
             double c[3];
             cross(ab, d, c);
@@ -273,7 +291,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
         else {
             for (int d = 0; d < 3; ++d) nrm[d] /= ln;
             double mx = -INFINITY, mn = INFINITY; int imx = -1, imn = -1;
-            for (int k = tid; k < m; k += NT) {
+            for (int k = tid; k < m; k += G::BT) {
                 const double sd = nrm[0] * (S.hp[3 * k] - A[0]) + nrm[1] * (S.hp[3 * k + 1] - A[1]) + nrm[2] * (S.hp[3 * k + 2] - A[2]);
                 if (sd > mx) { mx = sd; imx = k; }
                 if (sd < mn) { mn = sd; imn = k; }
@@ -288,19 +306,19 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                 // the plane (Qhull keeps those as vertices; anything flatter than round-off it rejects outright)
                 flat3 = true;
                 if (tid == 0) { if (fabs(dmx) > tolf) S.hflag[gmx] = 2; if (fabs(dmn) > tolf) S.hflag[gmn] = 2; }   // 2 = kept, not a visited hull vertex
-                __syncthreads();
+                G::sync();
             }
         }
     }
     if (!flat3) {
         if (m > HULL3_MAX) {  // beyond the brute-force limit: keep every point (superset of the hull)
-            for (int k = tid; k < m; k += NT) S.hflag[k] = 1;
-            __syncthreads();
+            for (int k = tid; k < m; k += G::BT) S.hflag[k] = 1;
+            G::sync();
             return;
         }
         // supporting-plane test over all triples
         const int ntri = m * m * m;
-        for (int e = tid; e < ntri; e += NT) {
+        for (int e = tid; e < ntri; e += G::BT) {
             const int i = e / (m * m), j = (e / m) % m, k = e % m;
             if (!(i < j && j < k)) continue;
             const double u[3] = {S.hp[3 * j] - S.hp[3 * i], S.hp[3 * j + 1] - S.hp[3 * i + 1], S.hp[3 * j + 2] - S.hp[3 * i + 2]};
@@ -316,7 +334,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
             }
             if (!(pos && neg)) { S.hflag[i] = 1; S.hflag[j] = 1; S.hflag[k] = 1; }
         }
-        __syncthreads();
+        G::sync();
         return;
     }
     // ---- 2-D: drop the coordinate of least variance (first index on ties, torch.argmin) ---------
@@ -329,15 +347,15 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
     if (!collinear) {
         // start: lexicographic minimum
         double k0 = INFINITY; int k0i = -1;
-        for (int k = tid; k < m; k += NT) if (S.hp[3 * k + c0] < k0) { k0 = S.hp[3 * k + c0]; k0i = k; }
+        for (int k = tid; k < m; k += G::BT) if (S.hp[3 * k + c0] < k0) { k0 = S.hp[3 * k + c0]; k0i = k; }
         const int i0 = block_argmin(k0, k0i, S);
         const double x0 = S.hp[3 * i0 + c0];
         k0 = INFINITY; k0i = -1;
-        for (int k = tid; k < m; k += NT) if (S.hp[3 * k + c0] == x0 && S.hp[3 * k + c1] < k0) { k0 = S.hp[3 * k + c1]; k0i = k; }
+        for (int k = tid; k < m; k += G::BT) if (S.hp[3 * k + c0] == x0 && S.hp[3 * k + c1] < k0) { k0 = S.hp[3 * k + c1]; k0i = k; }
         iS = block_argmin(k0, k0i, S);
         // collinearity: farthest point from the start, then max distance to that line
         key = -1.0; ki = -1;
-        for (int k = tid; k < m; k += NT) {
+        for (int k = tid; k < m; k += G::BT) {
             const double d0 = S.hp[3 * k + c0] - S.hp[3 * iS + c0], d1 = S.hp[3 * k + c1] - S.hp[3 * iS + c1];
             if (d0 * d0 + d1 * d1 > key) { key = d0 * d0 + d1 * d1; ki = k; }
         }
@@ -347,7 +365,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
         if (!(le > tolf)) collinear = true;
         else {
             double mx = 0.0;
-            for (int k = tid; k < m; k += NT)
+            for (int k = tid; k < m; k += G::BT)
                 mx = fmax(mx, fabs(e0 * (S.hp[3 * k + c1] - S.hp[3 * iS + c1]) - e1 * (S.hp[3 * k + c0] - S.hp[3 * iS + c0])) / le);
             if (!(block_max(mx, S) > tolf)) collinear = true;
         }
@@ -359,7 +377,7 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
             if (tid == 0) S.hflag[cur] = 1;
             const double cx = S.hp[3 * cur + c0], cy = S.hp[3 * cur + c1];
             int best = -1; double bx = 0, by = 0;
-            for (int k = tid; k < m; k += NT) {
+            for (int k = tid; k < m; k += G::BT) {
                 const double qx = S.hp[3 * k + c0] - cx, qy = S.hp[3 * k + c1] - cy;
                 const double lq = qx * qx + qy * qy;
                 if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
@@ -368,8 +386,8 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                 if (cr < -1e-9 * sqrt(lb * lq) || (fabs(cr) <= 1e-9 * sqrt(lb * lq) && lq > lb)) { best = k; bx = qx; by = qy; }
             }
             S.red_i[tid] = best;
-            __syncthreads();
-            for (int s = NT / 2; s > 0; s >>= 1) {
+            G::sync();
+            for (int s = G::BT / 2; s > 0; s >>= 1) {
                 if (tid < s) {
                     const int a = S.red_i[tid], b = S.red_i[tid + s];
                     if (b >= 0) {
@@ -382,11 +400,11 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
                         }
                     }
                 }
-                __syncthreads();
+                G::sync();
             }
             const int nxt = S.red_i[0];
             const int seen = nxt >= 0 ? (S.hflag[nxt] == 1) : 0;
-            __syncthreads();   // every thread has read red_i / hflag before thread 0 flags the next vertex
+            G::sync();   // every thread has read red_i / hflag before thread 0 flags the next vertex
             if (nxt < 0 || nxt == iS || seen) break;
             {   // coincident with the start (shared mesh vertices produce exact duplicates): the loop is closed
                 const double dx = S.hp[3 * nxt + c0] - S.hp[3 * iS + c0], dy = S.hp[3 * nxt + c1] - S.hp[3 * iS + c1];
@@ -394,13 +412,13 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
             }
             cur = nxt;
         }
-        __syncthreads();
+        G::sync();
         return;
     }
     // ---- 1-D: drop the next least-variance coordinate, keep min (and max if the spread > eps) ---
     const int keep = (var[c1] < var[c0]) ? c0 : c1;  // argmin over the remaining two drops the smaller
     double kmin = INFINITY, kmax = -INFINITY; int imin = -1, imax = -1;
-    for (int k = tid; k < m; k += NT) {
+    for (int k = tid; k < m; k += G::BT) {
         const double v = S.hp[3 * k + keep];
         if (v < kmin) { kmin = v; imin = k; }
         if (v > kmax) { kmax = v; imax = k; }
@@ -410,16 +428,16 @@ __device__ void cluster_hull(Scratch &S, int m, double eps)
         S.hflag[gmin] = 1;
         if (S.hp[3 * gmax + keep] - S.hp[3 * gmin + keep] > eps) S.hflag[gmax] = 1;
     }
-    __syncthreads();
+    G::sync();
 }
 
 // ---- the narrow phase -------------------------------------------------------------------------
-__device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
+template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S, int item, int slot_id)
 {
-#define STAMP(i) do { if (W.dbg_stamps && threadIdx.x == 0) W.dbg_stamps[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (W.dbg_stamps && G::tid() == 0) W.dbg_stamps[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
     STAMP(0);
     const int np = npairs_of(W.nb);
-    const int sc = item / np, dp = item % np, tid = threadIdx.x;
+    const int sc = item / np, dp = item % np, tid = G::tid();
     int a, b;
     pair_of(dp, W.nb, a, b);
     int *pc_count = W.pc_count + (size_t)sc * np + dp;
@@ -427,9 +445,10 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
     load_body(W, sc, a, A);
     load_body(W, sc, b, Bd);
     const int MC = W.max_cand;
-    int *cface = W.cand_face + ((size_t)sc * np + dp) * 2 * MC, *kface = cface + MC;
-    int *cstate = W.cand_state + ((size_t)sc * np + dp) * MC;
-    double *cb = W.cand_buf + ((size_t)sc * np + dp) * DSS_CAND_FIELDS * MC;
+    // candidate scratch belongs to the resident group, not to the item: it is reused item after item and stays in L2
+    int *cface = W.cand_face + (size_t)slot_id * 2 * MC, *kface = cface + MC;
+    int *cstate = W.cand_state + (size_t)slot_id * MC;
+    double *cb = W.cand_buf + (size_t)slot_id * DSS_CAND_FIELDS * MC;
 #define CB(f, k) cb[(size_t)(f) * MC + (k)]
     const double sB = Bd.g.shape.scale;
 
@@ -451,7 +470,8 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
     Region reg;
     region_of(A.g, Bd.g, 1e-9, reg);
     const double *fbox = W.fch_box + (size_t)W.mesh_fch_off[A.mesh] * 6;
-    const int nch = (A.nf + NT - 1) / NT, lane = tid & 63, wv = tid >> 6;
+    constexpr int RUN = 256;   // faces per culling box (engine.mesh_table CHUNK)
+    const int nch = (A.nf + RUN - 1) / RUN, lane = tid & 63, wv = tid >> 6;
     auto test_face = [&](int f, double pqr[3][3]) -> int {
         const double *c = W.fcent + (size_t)(A.foff + f) * 3;
         double cb2[3];
@@ -475,61 +495,63 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
-    if (nch <= MAX_CH) {
+    if (nch <= G::CHCAP) {
         // runs that can hold a candidate: tested in parallel (one culling box per thread), kept in order
         int npass = 0;
-        for (int base = 0; base < nch; base += NT) {
+        for (int base = 0; base < nch; base += G::BT) {
             const int ch = base + tid;
             const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6);
             const int slot = compact_slot(hit, npass, S);
             if (slot >= 0) S.hidx[slot] = ch;
         }
         unsigned long long *words = reinterpret_cast<unsigned long long *>(S.hp);   // [npass][4]
-        __syncthreads();
-        for (int i = 0; i < npass; ++i) {
-            const int f = S.hidx[i] * NT + tid;
-            double pqr[3][3];
-            const int flag = f < A.nf ? test_face(f, pqr) : 0;
-            const unsigned long long w = __ballot(flag);
-            if (lane == 0) words[i * 4 + wv] = w;
-        }
-        __syncthreads();
+        G::sync();
+        for (int i = 0; i < npass; ++i)
+            for (int sub = wv; sub < 4; sub += G::NW) {
+                const int f = S.hidx[i] * RUN + sub * 64 + lane;
+                double pqr[3][3];
+                const int flag = f < A.nf ? test_face(f, pqr) : 0;
+                const unsigned long long w = __ballot(flag);
+                if (lane == 0) words[i * 4 + sub] = w;
+            }
+        G::sync();
         // exclusive scan of the popcounts: thread t owns words [t*per, (t+1)*per)
-        const int nw = npass * 4, per = (nw + NT - 1) / NT;
+        const int nw = npass * 4, per = (nw + G::BT - 1) / G::BT;
         int mine = 0;
         for (int e = tid * per; e < (tid + 1) * per && e < nw; ++e) mine += __popcll(words[e]);
         S.red_i[tid] = mine;
-        __syncthreads();
-        if (tid == 0) { int run = 0; for (int t = 0; t < NT; ++t) { const int v = S.red_i[t]; S.red_i[t] = run; run += v; } S.wave_tot[0] = run; }
-        __syncthreads();
+        G::sync();
+        if (tid == 0) { int run = 0; for (int t = 0; t < G::BT; ++t) { const int v = S.red_i[t]; S.red_i[t] = run; run += v; } S.wave_tot[0] = run; }
+        G::sync();
         ncand = S.wave_tot[0];
         {
             int run = S.red_i[tid];
             for (int e = tid * per; e < (tid + 1) * per && e < nw; ++e) { S.woff[e] = run; run += __popcll(words[e]); }
         }
-        __syncthreads();
+        G::sync();
         if (ncand > 0)
-            for (int i = 0; i < npass; ++i) {
-                const unsigned long long w = words[i * 4 + wv];
-                if (!((w >> lane) & 1ull)) continue;
-                const int slot = S.woff[i * 4 + wv] + __popcll(w & ((1ull << lane) - 1ull));
-                if (slot >= MC) continue;
-                const int f = S.hidx[i] * NT + tid;
-                double pqr[3][3];
-                test_face(f, pqr);
-                cface[slot] = f;
-                for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
-            }
+            for (int i = 0; i < npass; ++i)
+                for (int sub = wv; sub < 4; sub += G::NW) {
+                    const unsigned long long w = words[i * 4 + sub];
+                    if (!((w >> lane) & 1ull)) continue;
+                    const int slot = S.woff[i * 4 + sub] + __popcll(w & ((1ull << lane) - 1ull));
+                    if (slot >= MC) continue;
+                    const int f = S.hidx[i] * RUN + sub * 64 + lane;
+                    double pqr[3][3];
+                    test_face(f, pqr);
+                    cface[slot] = f;
+                    for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
+                }
         if (ncand > MC) { over |= 1; ncand = MC; }
         if (tid == 0) { W.pc_stats[((size_t)sc * np + dp) * 2] = npass; W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = ncand; }
-        __syncthreads();
+        G::sync();
     } else {
-        for (int base = 0; base < A.nf; base += NT) {
-            if (!box_hits(reg, fbox + (size_t)(base / NT) * 6)) continue;
+        for (int base = 0; base < A.nf; base += G::BT) {
+            if (!box_hits(reg, fbox + (size_t)(base / RUN) * 6)) continue;
             const int f = base + tid;
             double pqr[3][3];
             const int flag = f < A.nf ? test_face(f, pqr) : 0;
-            if (!__syncthreads_or(flag)) continue;
+            if (!G::any(flag)) continue;
             const int slot = compact_slot(flag, ncand, S);
             if (slot >= 0 && slot < MC) {
                 cface[slot] = f;
@@ -538,8 +560,8 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
             if (ncand > MC) { over |= 1; ncand = MC; }
         }
     }
-    if (ncand == 0) { if (tid == 0) *pc_count = 0; return; }
-    __syncthreads();
+    if (ncand == 0) { if (tid == 0) *pc_count = 0; return 0; }
+    G::sync();
     STAMP(1);
 
     // ---- 2. Frank-Wolfe (contacts.py:57-82) -----------------------------------------------------
@@ -589,7 +611,7 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
     int nmov = 0;
     {
         int vote = 0;
-        for (int base = 0; base < ncand; base += NT) {
+        for (int base = 0; base < ncand; base += G::BT) {
             const int k = base + tid;
             float gm = 0.0f; int bi = 0, pen = 0;
             if (k < ncand) {
@@ -601,22 +623,22 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
             }
             const unsigned long long bm = __ballot(gm != 0.0f), bp = __ballot(pen);
             if ((tid & 63) == 0) S.vote[0][tid >> 6] = (bm != 0ull ? 1 : 0) | (bp != 0ull ? 2 : 0);
-            __syncthreads();
-            for (int w = 0; w < NT / 64; ++w) vote |= S.vote[0][w];
+            G::sync();
+            for (int w = 0; w < G::BT / 64; ++w) vote |= S.vote[0][w];
             const int slot = compact_slot(gm != 0.0f, nmov, S);
-            if (slot >= 0 && slot < 1024) S.hidx[slot] = k;
+            if (slot >= 0 && slot < G::HCAP) S.hidx[slot] = k;
         }
-        __syncthreads();
+        G::sync();
         if (vote & 2) {
             // a penetrating point in iteration 0: the reference leaves the loop BEFORE the update; undo it
-            for (int k = tid; k < ncand; k += NT) {
+            for (int k = tid; k < ncand; k += G::BT) {
                 const float gm = (float)CB(25, k);
                 if (gm != 0.0f) { Cand c; load_c(c, k); init_c(c); store_c(c, k); }
             }
             nmov = 0;
         }
-        if (nmov > 1024) { over |= 2; nmov = 1024; }
-        __syncthreads();
+        if (nmov > G::HCAP) { if (G::BT == 64) return 1; over |= 2; nmov = G::HCAP; }
+        G::sync();
     }
     // the mover owned by this thread (if any) stays in registers for the remaining iterations
     Cand m0;
@@ -632,7 +654,7 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
             any_pen |= pen; moving |= gam[0] != 0.0f;
             if (gam[0] == 0.0f) alive0 = 0;     // froze: x no longer changes, every later evaluation repeats this one
         }
-        for (int j = tid + NT; j < nmov; j += NT, ++q) {
+        for (int j = tid + G::BT; j < nmov; j += G::BT, ++q) {
             const int k = S.hidx[j];
             gam[q] = 0.0f; ind[q] = 0;
             if (cstate[k] < 0) continue;
@@ -643,20 +665,20 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         }
         const unsigned long long bm = __ballot(moving), bp = __ballot(any_pen);
         if ((tid & 63) == 0) S.vote[iter & 1][tid >> 6] = (bm != 0ull ? 1 : 0) | (bp != 0ull ? 2 : 0);
-        __syncthreads();
+        G::sync();
         int vote = 0;
-        for (int w = 0; w < NT / 64; ++w) vote |= S.vote[iter & 1][w];
+        for (int w = 0; w < G::BT / 64; ++w) vote |= S.vote[iter & 1][w];
         if (!(vote & 1) || (vote & 2)) break;   // all gamma == 0, or a penetrating point (contacts.py:74-77)
         if (gam[0] != 0.0f) apply_c(m0, gam[0], ind[0]);
         q = 1;
-        for (int j = tid + NT; j < nmov; j += NT, ++q) {
+        for (int j = tid + G::BT; j < nmov; j += G::BT, ++q) {
             if (gam[q] == 0.0f) continue;
             const int k = S.hidx[j];
             Cand c; load_c(c, k); apply_c(c, gam[q], ind[q]); store_c(c, k);
         }
     }
     if (k0 >= 0) store_c(m0, k0);
-    __syncthreads();
+    G::sync();
 
     STAMP(2);
     // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) -------------------
@@ -667,7 +689,7 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         quat_mul(qbi, A.g.q, qrel);
     }
     int ncon = 0;
-    for (int base = 0; base < ncand; base += NT) {
+    for (int base = 0; base < ncand; base += G::BT) {
         const int k = base + tid;
         int flag = 0;
         double abc[3] = {0, 0, 0};
@@ -686,29 +708,29 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
             query_sdf(Bd.g.shape, x, phi2, g2, false);
             flag = phi2 <= W.eps;
         }
-        if (!__syncthreads_or(flag)) continue;
+        if (!G::any(flag)) continue;
         const int slot = compact_slot(flag, ncon, S);
         if (slot >= 0) { kface[slot] = cface[k]; for (int i = 0; i < 3; ++i) CB(15 + i, slot) = abc[i]; }
     }
-    if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) atomicOr(W.overflow + sc, over); } return; }
-    __syncthreads();
+    if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) atomicOr(W.overflow + sc, over); } return 0; }
+    G::sync();
 
     STAMP(3);
     // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
     int bad = 0;
-    for (int k = tid; k < ncon; k += NT) {
+    for (int k = tid; k < ncon; k += G::BT) {
         const int *fv = W.faces + (size_t)(A.foff + kface[k]) * 3;
         double tri[3][3], n[3], p1[3], p2[3], pen;
         for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
         const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
         contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
-        for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; }
+        for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; CB(i, k) = p2[i]; }   // pqr (fields 0-8) is dead by now
         CB(24, k) = pen;
         if (!(pen <= W.tol)) bad = 1;
     }
-    if (__syncthreads_or(bad)) {
+    if (G::any(bad)) {
         if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
-        return;
+        return 0;
     }
 
     STAMP(4);
@@ -718,20 +740,20 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
         if (tid == 0) cstate[0] = -2;  // kept
         nkeep = ncon;
     } else {
-        for (int k = tid; k < ncon; k += NT) {
+        for (int k = tid; k < ncon; k += G::BT) {
             const double nn = sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
             cstate[k] = nn > 1e-12 ? 0 : -1;
         }
-        __syncthreads();
+        G::sync();
         for (int cl = 1; cl <= ncon; ++cl) {
             int mine = -1;
-            for (int k = tid; k < ncon; k += NT) if (cstate[k] == 0) { mine = k; break; }
+            for (int k = tid; k < ncon; k += G::BT) if (cstate[k] == 0) { mine = k; break; }
             const int seed = block_argmin(mine >= 0 ? (double)mine : INFINITY, mine, S);
             if (seed < 0) break;
             const double sn[3] = {CB(18, seed), CB(19, seed), CB(20, seed)};
             // gather the cluster (ascending) into the hull scratch
             int m = 0;
-            for (int base = 0; base < ncon; base += NT) {
+            for (int base = 0; base < ncon; base += G::BT) {
                 const int k = base + tid;
                 int in = 0;
                 if (k < ncon && cstate[k] == 0) {
@@ -741,21 +763,21 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
                 const int slot = compact_slot(in, m, S);
                 if (slot >= 0) {
                     cstate[k] = cl;
-                    if (slot < 1024) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = CB(21 + i, k); }
+                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = CB(21 + i, k); }
                 }
             }
-            __syncthreads();
-            if (m > 1024) { over |= 2; m = 1024; }
+            G::sync();
+            if (m > G::HCAP) { if (G::BT == 64) return 1; over |= 2; m = G::HCAP; }
             cluster_hull(S, m, W.eps);
-            for (int j = tid; j < m; j += NT) if (S.hflag[j]) cstate[S.hidx[j]] = -2;
-            __syncthreads();
+            for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) cstate[S.hidx[j]] = -2;
+            G::sync();
         }
-        for (int k = tid; k < ncon; k += NT) nkeep += (cstate[k] == -2);
+        for (int k = tid; k < ncon; k += G::BT) nkeep += (cstate[k] == -2);
         nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
     }
 
     STAMP(5);
-    // ---- 6. final geometry of the kept contacts, in ascending face order --------------------------
+    // ---- 6. the kept contacts (geometry from stage 4), in ascending face order --------------------
     // (the reference emits cluster by cluster in Qhull's vertex order, which is implementation
     //  defined; contact sets of a pair are compared as sets)
     int nout = 0;
@@ -764,61 +786,78 @@ __device__ void narrow_pair(const DssWorld &W, Scratch &S, int item)
     double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
     if (ncon <= 1) {
         if (tid == 0) {
-            const int *fv = W.faces + (size_t)(A.foff + kface[0]) * 3;
-            double tri[3][3], n[3], p1[3], p2[3], pen;
-            for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
-            const double abc[3] = {CB(15, 0), CB(16, 0), CB(17, 0)};
-            contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
             pf[0] = kface[0];
-            for (int i = 0; i < 3; ++i) { pabc[(size_t)i * MP] = abc[i]; pg[(size_t)i * MP] = n[i]; pg[(size_t)(3 + i) * MP] = p1[i]; pg[(size_t)(6 + i) * MP] = p2[i]; }
-            pg[(size_t)9 * MP] = pen;
+            for (int i = 0; i < 3; ++i) { pabc[(size_t)i * MP] = CB(15 + i, 0); pg[(size_t)i * MP] = CB(18 + i, 0); pg[(size_t)(3 + i) * MP] = CB(21 + i, 0); pg[(size_t)(6 + i) * MP] = CB(i, 0); }
+            pg[(size_t)9 * MP] = CB(24, 0);
         }
         nout = 1;
     } else {
-        for (int base = 0; base < ncon; base += NT) {
+        for (int base = 0; base < ncon; base += G::BT) {
             const int k = base + tid;
             const int flag = (k < ncon) && cstate[k] == -2;
-            if (!__syncthreads_or(flag)) continue;
+            if (!G::any(flag)) continue;
             const int slot = compact_slot(flag, nout, S);
             if (slot >= 0 && slot < MP) {
-                const int *fv = W.faces + (size_t)(A.foff + kface[k]) * 3;
-                double tri[3][3], n[3], p1[3], p2[3], pen;
-                for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
-                const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
-                contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
                 pf[slot] = kface[k];
                 for (int i = 0; i < 3; ++i) {
-                    pabc[(size_t)i * MP + slot] = abc[i];
-                    pg[(size_t)i * MP + slot] = n[i]; pg[(size_t)(3 + i) * MP + slot] = p1[i]; pg[(size_t)(6 + i) * MP + slot] = p2[i];
+                    pabc[(size_t)i * MP + slot] = CB(15 + i, k);
+                    pg[(size_t)i * MP + slot] = CB(18 + i, k); pg[(size_t)(3 + i) * MP + slot] = CB(21 + i, k); pg[(size_t)(6 + i) * MP + slot] = CB(i, k);
                 }
-                pg[(size_t)9 * MP + slot] = pen;
+                pg[(size_t)9 * MP + slot] = CB(24, k);
             }
         }
         if (nout > MP) { over |= 4; nout = MP; }
     }
     if (tid == 0) { *pc_count = nout; if (over) atomicOr(W.overflow + sc, over); }
     STAMP(6);
+    return 0;
 #undef STAMP
 #undef CB
 }
 
-// persistent: workgroups pull items off the active-pair list through a shared cursor (n_pairs[1]) so that the
-// long items (a 176 k-face floor against a box) do not leave a static-partition tail
+// persistent: groups pull items off the active-pair lists through shared cursors so that the long items (a 176 k-face
+// floor against a box) do not leave a static-partition tail.  n_pairs = {count, cursor} x {block list, wave list,
+// deferred list}; pair_list = three segments of B*npairs.  Every workgroup first helps with the block list (all four
+// wavefronts on one item), then its wavefronts split up and walk the wave list independently.  A wave item that
+// outgrows the wave-sized scratch is appended to the deferred list, which a second launch works off block-wise.
 #ifndef DSS_NP_WAVES
 #define DSS_NP_WAVES 3   // waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
-__global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W)
+union NpScratch {
+    ScratchT<BlockGroup> blk;
+    ScratchT<WaveGroup> wav[BlockGroup::NW];
+};
+template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W)
 {
-    __shared__ Scratch S;
+    __shared__ NpScratch S;
     __shared__ int s_item;
-    const int n = W.n_pairs[0];
+    const int cap = W.B * npairs_of(W.nb), seg = DEFERRED ? 2 : 0;
+    {
+        const int n = W.n_pairs[2 * seg];
+        const int *list = W.pair_list + (size_t)seg * cap;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_item = atomicAdd(W.n_pairs + 2 * seg + 1, 1);
+            __syncthreads();
+            const int it = s_item;
+            if (it >= n) break;
+            narrow_pair<BlockGroup>(W, S.blk, list[it], (int)blockIdx.x * BlockGroup::NW);
+        }
+    }
+    if (DEFERRED) return;
+    __syncthreads();   // nobody still reads the block scratch
+    const int n = W.n_pairs[2], lane = threadIdx.x & 63;
+    const int *list = W.pair_list + cap;
+    ScratchT<WaveGroup> &Sw = S.wav[threadIdx.x >> 6];
     for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(W.n_pairs + 1, 1);
-        __syncthreads();
-        const int it = s_item;
+        int it = 0;
+        if (lane == 0) it = atomicAdd(W.n_pairs + 3, 1);
+        it = __shfl(it, 0);
         if (it >= n) break;
-        narrow_pair(W, S, W.pair_list[it]);
+        const int item = list[it];
+        if (narrow_pair<WaveGroup>(W, Sw, item, (int)(blockIdx.x * BlockGroup::NW + (threadIdx.x >> 6))) && lane == 0)
+            W.pair_list[(size_t)2 * cap + atomicAdd(W.n_pairs + 4, 1)] = item;
+        dss_wave_sync();
     }
 }
 
@@ -857,19 +896,27 @@ __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *n
 }  // namespace
 
 namespace dss {
+// 256 CUs x DSS_NP_WAVES resident workgroups walk the work lists; every wavefront of the grid owns one scratch slot
+static inline int np_grid(int B, int nb)
+{
+    const long items = (long)B * nb * (nb - 1);
+    return (int)(items < 256 * DSS_NP_WAVES ? items : 256 * DSS_NP_WAVES);
+}
 // enqueue detection at the current pose; results land in (nc_out, body_out, ...)
 int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
                          double *geom_out, hipStream_t stream)
 {
     if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
-    (void)hipMemsetAsync(W.n_pairs, 0, 2 * sizeof(int), stream);   // [0] list length, [1] work cursor
+    (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // {count, cursor} x {block, wave, deferred}
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
     // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
-    static const int wgs_per_cu = getenv("DSS_NP_WGS_PER_CU") ? atoi(getenv("DSS_NP_WGS_PER_CU")) : DSS_NP_WAVES;
-    const int grid = W.B * np < 256 * wgs_per_cu ? W.B * np : 256 * wgs_per_cu;
-    hipLaunchKernelGGL(narrowphase_kernel, dim3(grid), dim3(NT), 0, stream, W);
+    const int grid = np_grid(W.B, W.nb);
+    hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);
+    hipLaunchKernelGGL(narrowphase_kernel<true>, dim3(grid), dim3(NT), 0, stream, W);   // normally finds an empty list
     hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 }  // namespace dss
+
+extern "C" int dss_np_slots(int B, int nb) { return dss::np_grid(B, nb) * 4; }

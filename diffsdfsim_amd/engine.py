@@ -157,6 +157,8 @@ class BatchEngine:
         if L.dss_world_sizeof() != ctypes.sizeof(abi.DssWorld):
             raise RuntimeError("DssWorld layout mismatch: library %d bytes, python mirror %d bytes"
                                % (L.dss_world_sizeof(), ctypes.sizeof(abi.DssWorld)))
+        if L.dss_np_slots(int(B), int(nb)) != abi.np_slots(int(B), int(nb)):
+            raise RuntimeError("narrow-phase slot count mismatch between the library and its python mirror")
         L.dss_lcp_contact_workspace_bytes.restype = ctypes.c_size_t
         nbytes = L.dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fric_dirs)
         self.lcp_ws = self.be.zeros((nbytes,), np.uint8)

@@ -49,6 +49,11 @@ class DssWorld(ctypes.Structure):
 NP_DTYPE = {"pd": np.float64, "pi": np.int32, "pb": np.uint8}
 
 
+def np_slots(B, nb):
+    """Scratch slots of the persistent narrow phase = wavefronts of its grid (mirrors dss_np_slots)."""
+    return 4 * min(B * nb * (nb - 1), 256 * 3)
+
+
 def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF, NFC=1, NVC=1):
     """Shapes of every array the kernels touch (state, scratch, tape)."""
     npair = nb * (nb - 1)
@@ -69,11 +74,11 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
         "pose0": (B, nb, 7), "vel0": (B, nb, 6),
         "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
         "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
-        "ovl": (B, nb, nb), "pair_list": (B * npair,), "n_pairs": (2,), "invalid": (B,), "overflow": (B,),
+        "ovl": (B, nb, nb), "pair_list": (3 * B * npair,), "n_pairs": (6,), "invalid": (B,), "overflow": (B,),
         "pc_count": (B, npair), "pc_stats": (B, npair, 2), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
         "pc_geom": (B, npair, 10, max_pc),
-        "cand_face": (B, npair, 2, max_cand), "cand_state": (B, npair, max_cand),
-        "cand_buf": (B, npair, CAND_FIELDS, max_cand),
+        "cand_face": (np_slots(B, nb), 2, max_cand), "cand_state": (np_slots(B, nb), max_cand),
+        "cand_buf": (np_slots(B, nb), CAND_FIELDS, max_cand),
     }
     if max_sub > 0:
         s.update({

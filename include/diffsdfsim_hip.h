@@ -162,8 +162,9 @@ typedef struct DssWorld {
     int *cop_body, *lcp_iters, *lcp_status;
     /* narrow phase scratch */
     int *ovl;                /* [B][nb][nb] overlap flags */
-    int *pair_list;          /* [B*npairs] active (scene*npairs + directed pair) work items of this attempt */
-    int *n_pairs;            /* [2]: list length, work cursor of the persistent narrow phase */
+    int *pair_list;          /* [3][B*npairs] active (scene*npairs + directed pair) work items of this attempt:
+                                workgroup items, wavefront items, wavefront items deferred to a workgroup */
+    int *n_pairs;            /* [3][2]: list length, work cursor of each list */
     int *invalid;            /* [B] penetration > tol found in this attempt */
     int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
@@ -171,9 +172,9 @@ typedef struct DssWorld {
     int *pc_face;            /* [B][npairs][max_pc] */
     double *pc_abc;          /* [B][npairs][3][max_pc] */
     double *pc_geom;         /* [B][npairs][10][max_pc] */
-    int *cand_face;          /* [B][npairs][2][max_cand] candidate faces / contact faces */
-    int *cand_state;         /* [B][npairs][max_cand] contact list / cluster ids */
-    double *cand_buf;        /* [B][npairs][DSS_CAND_FIELDS][max_cand] */
+    int *cand_face;          /* [dss_np_slots()][2][max_cand] candidate faces / contact faces (per resident wavefront) */
+    int *cand_state;         /* [dss_np_slots()][max_cand] contact list / cluster ids */
+    double *cand_buf;        /* [dss_np_slots()][DSS_CAND_FIELDS][max_cand] */
     /* tape for the backward pass: slot-major, [max_sub][B][...] (NULL = do not record) */
     int max_sub;
     double *tp_pose, *tp_vel, *tp_dt, *tp_x, *tp_lam, *tp_slack, *tp_nu, *tp_abc, *tp_geom;
@@ -192,7 +193,9 @@ typedef struct DssWorld {
 #define DSS_SHAPE_SPHERE 1
 #define DSS_SHAPE_CYLINDER 2   /* shape_prm = (rad, height, -), axis = body z */
 
-size_t dss_world_sizeof(void);   /* sizeof(DssWorld): lets a binding check its mirror struct */
+size_t dss_world_sizeof(void);
+/* scratch slots the narrow phase needs for a batch of B scenes with nb bodies (sizes cand_face/cand_state/cand_buf) */
+int dss_np_slots(int B, int nb);   /* sizeof(DssWorld): lets a binding check its mirror struct */
 
 /* Start an outer step of length W->dt for every scene: t_end = t + dt, active = 1 (world.py:119-134). */
 int dss_step_begin(const DssWorld *W, void *stream);
