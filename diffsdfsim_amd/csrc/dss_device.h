@@ -7,6 +7,8 @@
 #include "hip_emu.h"
 // lanes of one emulated wavefront meet at every switch point
 inline void dss_wave_sync() { dss_emu::yield(); }
+inline int dss_uniform(int x) { return x; }
+inline double dss_uniform(double x) { return x; }
 #else
 #include <hip/hip_runtime.h>
 #define DSS_DYN_LDS(type, name) extern __shared__ __align__(16) type name[]
@@ -17,5 +19,11 @@ __device__ __forceinline__ void dss_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// a value every lane of the wavefront agrees on, moved to scalar registers
+__device__ __forceinline__ int dss_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double dss_uniform(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 #endif

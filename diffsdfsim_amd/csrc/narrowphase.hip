@@ -52,6 +52,15 @@ __device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
     for (int i = 0; i < 3; ++i) o.g.pos[i] = ps[4 + i];
     const double *prm = W.shape_prm + ((size_t)sc * W.nb + b) * 3;
     make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm);
+    // the same for every lane: keep it in scalar registers (frees ~60 VGPRs in the narrow phase)
+    for (int i = 0; i < 4; ++i) o.g.q[i] = dss_uniform(o.g.q[i]);
+    for (int i = 0; i < 3; ++i) {
+        o.g.pos[i] = dss_uniform(o.g.pos[i]);
+        o.g.shape.prm[i] = dss_uniform(o.g.shape.prm[i]);
+        o.g.shape.hd[i] = dss_uniform(o.g.shape.hd[i]);
+    }
+    o.g.shape.scale = dss_uniform(o.g.shape.scale);
+    o.g.shape.type = dss_uniform(o.g.shape.type);
     o.mesh = W.mesh_id[(size_t)sc * W.nb + b];
     o.voff = W.mesh_voff[o.mesh]; o.nv = W.mesh_nv[o.mesh];
     o.foff = W.mesh_foff[o.mesh]; o.nf = W.mesh_nf[o.mesh];
@@ -436,6 +445,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 {
 #define STAMP(i) do { if (W.dbg_stamps && G::tid() == 0) W.dbg_stamps[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
     STAMP(0);
+    item = dss_uniform(item); slot_id = dss_uniform(slot_id);
     const int np = npairs_of(W.nb);
     const int sc = item / np, dp = item % np, tid = G::tid();
     int a, b;
@@ -569,6 +579,8 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     // candidates than threads); further ones stream through the L2-resident scratch.  One barrier per
     // iteration: the two early-exit votes travel as ballots through a parity-double-buffered LDS word.
     struct Cand { double pqr[9], x[3], abc[3]; };
+    // vertex bi of the triangle, picked with selects: a run-time index would push the struct into scratch memory
+    auto vtx = [](const Cand &c, int bi, int i) { return bi == 0 ? c.pqr[i] : (bi == 1 ? c.pqr[3 + i] : c.pqr[6 + i]); };
     auto load_c = [&](Cand &c, int k) {
         for (int i = 0; i < 9; ++i) c.pqr[i] = CB(i, k);
         for (int i = 0; i < 3; ++i) { c.x[i] = CB(9 + i, k); c.abc[i] = CB(12 + i, k); }
@@ -583,7 +595,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             query_sdf(Bd.g.shape, c.pqr + 3 * v, phi, g, false);
             if (phi < best) { best = phi; bi = v; }
         }
-        for (int i = 0; i < 3; ++i) { c.x[i] = c.pqr[3 * bi + i]; c.abc[i] = (i == bi) ? 1.0 : 0.0; }
+        for (int i = 0; i < 3; ++i) { c.x[i] = vtx(c, bi, i); c.abc[i] = (i == bi) ? 1.0 : 0.0; }
     };
     // NOTE the reference forms gamma as python_float * bool_tensor (contacts.py:72-73), which torch
     // promotes to float32: the step sizes, and 1 - gamma, are float32-rounded.  Replicated bit for bit.
@@ -595,14 +607,14 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             const double d = c.pqr[3 * v] * g[0] + c.pqr[3 * v + 1] * g[1] + c.pqr[3 * v + 2] * g[2];
             if (d < bestd) { bestd = d; bi = v; }
         }
-        const double impr = (c.x[0] - c.pqr[3 * bi]) * g[0] + (c.x[1] - c.pqr[3 * bi + 1]) * g[1] + (c.x[2] - c.pqr[3 * bi + 2]) * g[2];
+        const double impr = (c.x[0] - vtx(c, bi, 0)) * g[0] + (c.x[1] - vtx(c, bi, 1)) * g[1] + (c.x[2] - vtx(c, bi, 2)) * g[2];
         gm = (fabs(impr) > W.tol) ? (float)(2.0 / (iter + 2.0)) : 0.0f;
         pen = phi < -W.tol;
     };
     auto apply_c = [&](Cand &c, float g32, int bi) {
         const double gm = (double)g32, om = (double)(1.0f - g32);
-        for (int i = 0; i < 3; ++i) { c.x[i] = om * c.x[i] + gm * c.pqr[3 * bi + i]; c.abc[i] *= om; }
-        c.abc[bi] += gm;
+        for (int i = 0; i < 3; ++i) { c.x[i] = om * c.x[i] + gm * vtx(c, bi, i); c.abc[i] *= om; }
+        for (int i = 0; i < 3; ++i) if (i == bi) c.abc[i] += gm;
     };
     // iteration 0 for everybody; afterwards only candidates that still move are touched: a candidate whose
     // |improvement| <= tol keeps x, so every later evaluation repeats the same numbers and gamma stays 0
