@@ -482,12 +482,15 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     const double *fbox = W.fch_box + (size_t)W.mesh_fch_off[A.mesh] * 6;
     constexpr int RUN = 256;   // faces per culling box (engine.mesh_table CHUNK)
     const int nch = (A.nf + RUN - 1) / RUN, lane = tid & 63, wv = tid >> 6;
-    auto test_face = [&](int f, double pqr[3][3]) -> int {
-        const double *c = W.fcent + (size_t)(A.foff + f) * 3;
+    // cheap pre-test: the face centroid (pose-invariant, composite transform) lies in b's query cube (+ margin)
+    auto cull_face = [&](const double *c) -> int {
         double cb2[3];
         for (int i = 0; i < 3; ++i) cb2[i] = R12[3 * i] * c[0] + R12[3 * i + 1] * c[1] + R12[3 * i + 2] * c[2] + t12[i];
         const double lim = sB + 1e-9 * (1.0 + sB);
-        if (!(fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim)) return 0;
+        return fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim;
+    };
+    // the reference's candidate test (contacts.py:44-52) in its own order of operations
+    auto full_face = [&](int f, double pqr[3][3]) -> int {
         const int *fv = W.faces + (size_t)(A.foff + f) * 3;
         double x[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) {
@@ -505,7 +508,57 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
-    if (nch <= G::CHCAP) {
+    auto test_face = [&](int f, double pqr[3][3]) -> int {
+        return cull_face(W.fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
+    };
+    if (G::BT == 64 && nch <= G::CHCAP) {
+        // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
+        // flight, survivors packed in ascending order into LDS; (b) the full test on dense lanes.
+        int npass = 0;
+        for (int base = 0; base < nch; base += G::BT) {
+            const int ch = base + tid;
+            const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6);
+            const int slot = compact_slot(hit, npass, S);
+            if (slot >= 0) S.hidx[slot] = ch;
+        }
+        G::sync();
+        int *surv = reinterpret_cast<int *>(S.hp);
+        constexpr int SCAP = (int)(sizeof(S.hp) / sizeof(int)) - 4 * 64;
+        int nsurv = 0;
+        auto flush = [&]() {
+            G::sync();
+            for (int base = 0; base < nsurv; base += 64) {
+                const int f = base + lane < nsurv ? surv[base + lane] : -1;
+                double pqr[3][3];
+                const int flag = f >= 0 ? full_face(f, pqr) : 0;
+                const int slot = compact_slot(flag, ncand, S);
+                if (slot >= 0 && slot < MC) {
+                    cface[slot] = f;
+                    for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
+                }
+            }
+            G::sync();
+            nsurv = 0;
+        };
+        for (int i = 0; i < npass; ++i) {
+            const int f0 = S.hidx[i] * RUN + lane;
+            double c[4][3];
+            for (int sub = 0; sub < 4; ++sub) {
+                const int f = f0 + 64 * sub < A.nf ? f0 + 64 * sub : A.nf - 1;
+                for (int d = 0; d < 3; ++d) c[sub][d] = W.fcent[(size_t)(A.foff + f) * 3 + d];
+            }
+            for (int sub = 0; sub < 4; ++sub) {
+                const int ok = f0 + 64 * sub < A.nf && cull_face(c[sub]);
+                const int slot = compact_slot(ok, nsurv, S);
+                if (slot >= 0) surv[slot] = f0 + 64 * sub;
+            }
+            if (nsurv > SCAP) flush();
+        }
+        if (nsurv > 0) flush();
+        if (ncand > MC) { over |= 1; ncand = MC; }
+        if (tid == 0) { W.pc_stats[((size_t)sc * np + dp) * 2] = npass; W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = ncand; }
+        G::sync();
+    } else if (nch <= G::CHCAP) {
         // runs that can hold a candidate: tested in parallel (one culling box per thread), kept in order
         int npass = 0;
         for (int base = 0; base < nch; base += G::BT) {
