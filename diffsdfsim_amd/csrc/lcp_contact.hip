@@ -42,6 +42,16 @@ __device__ long long *g_lcp_stamps = nullptr;
 namespace {
 using namespace dss;
 
+// The contact index of a pass, hidden from loop-invariant code motion: otherwise every per-contact address of
+// every pass (hundreds of 64-bit values) is hoisted out of the IPM iteration loop and spilled to scratch memory.
+__device__ __forceinline__ int opaque_lane(int lane)
+{
+#if !defined(DSS_EMU)
+    asm volatile("" : "+v"(lane));
+#endif
+    return lane;
+}
+
 template <int ND> struct Geo {
     static constexpr int NR = 2 * ND + 2;       // rows per contact: normal, ND +dirs, ND -dirs, cone
     static constexpr int NF = 3 * (1 + ND) + 8; // operand fields per contact
@@ -291,34 +301,56 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
     // contacts arrive grouped by (body1, body2) (detection emits them pair by pair): the 12x12 local sum of a
     // run is kept in registers (3 values per lane) and added to K once per run instead of once per contact
     if (lane < 48) {
-        int pb1 = -1, pb2 = -1;
-        double acc[3] = {0.0, 0.0, 0.0};
-        auto flush = [&]() {
-            if (pb1 < 0) return;
-            const int row = 6 * (br ? pb2 : pb1) + rr, col = 6 * (bc ? pb2 : pb1) + 3 * kind;
+        // One contact's term of this lane's three entries, split into its LDS reads and its arithmetic so that the
+        // unrolled loop below has the reads of four contacts in flight at once (a single wavefront per SIMD has
+        // nothing else to hide the LDS round trip behind).  Branch-free: rows 3-5 use k1 = 1, k2 = 0.
+        const int ia = rr < 3 ? (rr + 2) % 3 : rr - 3, ib = rr < 3 ? (rr + 1) % 3 : 0;
+        struct Rd { double pa, pb, Ca[3], Cb[3], pc[3]; };
+        auto rd = [&](int c, Rd &t) {
+            const double *C = L.cw + 9 * c, *pr = L.pbuf + 6 * c + 3 * br, *pc = L.pbuf + 6 * c + 3 * bc;
+            t.pa = pr[ib]; t.pb = pr[ia];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { L.K[row * lda + col + j] += sgn * acc[j]; acc[j] = 0.0; }
+            for (int j = 0; j < 3; ++j) { t.Ca[j] = C[3 * ia + j]; t.Cb[j] = C[3 * ib + j]; t.pc[j] = pc[j]; }
         };
-        for (int c = 0; c < nc; ++c) {
+        auto term = [&](const Rd &t, double *o) {
+            const double k1 = rr < 3 ? t.pa : 1.0, k2 = rr < 3 ? t.pb : 0.0;
+            double a[3], x[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[j] = k1 * t.Ca[j] - k2 * t.Cb[j];   // rr < 3: row rr of X(p) C = (p x C[:,j])[rr]
+            cross3(t.pc, a, x);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = kind == 0 ? x[j] : a[j];
+        };
+        int c = 0;
+        while (c < nc) {
             const int b1 = cbody[c], b2 = cbody[L.maxc + c];
-            if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
-            const double *C = L.cw + 9 * c;
-            const double *pr = L.pbuf + 6 * c + 3 * br, *pc = L.pbuf + 6 * c + 3 * bc;
-            double a[3], o[3];
-            if (rr < 3) {  // row rr of X(p) C : (p x C[:,j])[rr]
-                const int i1 = (rr + 1) % 3, i2 = (rr + 2) % 3;
+            int e = c + 1;
+            while (e < nc && cbody[e] == b1 && cbody[L.maxc + e] == b2) ++e;
+            double acc[3] = {0.0, 0.0, 0.0};
+            for (; c + 4 <= e; c += 4) {
+                Rd t[4];
+                double o[4][3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) a[j] = pr[i1] * C[3 * i2 + j] - pr[i2] * C[3 * i1 + j];
-            } else {
+                for (int u = 0; u < 4; ++u) rd(c + u, t[u]);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) a[j] = C[3 * (rr - 3) + j];
+                for (int u = 0; u < 4; ++u) term(t[u], o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] += o[u][j];
             }
-            if (kind == 0) cross3(pc, a, o);
-            else { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+            for (; c < e; ++c) {
+                Rd t;
+                double o[3];
+                rd(c, t);
+                term(t, o);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] += o[j];
+                for (int j = 0; j < 3; ++j) acc[j] += o[j];
+            }
+            const int row = 6 * (br ? b2 : b1) + rr, col = 6 * (bc ? b2 : b1) + 3 * kind;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.K[row * lda + col + j] += sgn * acc[j];
         }
-        flush();
     }
     __syncthreads();
 }
@@ -571,7 +603,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
     for (it = 0; it < max_iter; ++it) {
         // ---- residuals (batch.py:117-131) and the affine right-hand side ---------------------
         double acc_rz = 0.0, acc_sz = 0.0;
-        for (int c = lane; c < nc; c += WAVE) {
+        for (int c = opaque_lane(lane); c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
             double s[NR], z[NR], gx[NR], fz[NR], a[NR], t[NR], u[NR], vr[3], w[3];
@@ -619,7 +651,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
             best = resid; have_best = 1; not_improved = 0;
             if (lane < nz) x_out[lane] = L.xv[lane];
             else if (lane < n) nu[lane - nz] = L.xv[lane];
-            for (int c = lane; c < nc; c += WAVE)
+            for (int c = opaque_lane(lane); c < nc; c += WAVE)
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
                     lam[(size_t)q * maxc + c] = cz[(size_t)q * maxc + c];
@@ -633,7 +665,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 
         // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
         __syncthreads();
-        for (int c = lane; c < nc; c += WAVE) {
+        for (int c = opaque_lane(lane); c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
             double a[NR], C[9];
@@ -658,7 +690,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         __syncthreads();
         LSTAMP(7);
         StepAcc stz, sts;
-        for (int c = lane; c < nc; c += WAVE) {
+        for (int c = opaque_lane(lane); c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
             double s[NR], z[NR], a[NR], r[NR], u[NR], vr[3];
@@ -684,7 +716,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         __syncthreads();
         LSTAMP(8);
         double t3 = 0.0;
-        for (int c = lane; c < nc; c += WAVE)
+        for (int c = opaque_lane(lane); c < nc; c += WAVE)
 #pragma unroll
             for (int q = 0; q < NR; ++q)
                 t3 += (cs[(size_t)q * maxc + c] + alpha * cds[(size_t)q * maxc + c]) *
@@ -693,7 +725,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         double sig = t3 / sz;
         sig = sig * sig * sig;
         // ---- corrector (batch.py:194-205): rx = rz = ry = 0, rs = (-mu sig + ds dz)/s ----------
-        for (int c = lane; c < nc; c += WAVE) {
+        for (int c = opaque_lane(lane); c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
             double a[NR], t[NR], u[NR], w[3], ag = 1.0;
@@ -721,7 +753,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         __syncthreads();
         LSTAMP(10);
         StepAcc stz2, sts2;
-        for (int c = lane; c < nc; c += WAVE) {
+        for (int c = opaque_lane(lane); c < nc; c += WAVE) {
             Geo<ND> g;
             load_geo<ND>(g, cop, cbody, maxc, c);
             double s[NR], z[NR], a[NR], r[NR], u[NR], rs2[NR], vr[3];
@@ -749,7 +781,7 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
         __syncthreads();
         LSTAMP(11);
         if (lane < n) L.xv[lane] += alpha * (L.dxa[lane] + L.sol[lane]);
-        for (int c = lane; c < nc; c += WAVE)
+        for (int c = opaque_lane(lane); c < nc; c += WAVE)
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 cs[(size_t)q * maxc + c] += alpha * cds[(size_t)q * maxc + c];

@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 assert torch.equal(xo, xi.view(4096, 64).max(1).values), "DPP wave max selftest FAILED"
 print("DPP wave max selftest ok")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-E = BatchEngine(scenes.box_stack(B, nbox=7, seed=1), maxc=192, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
+E = BatchEngine(scenes.box_stack(B, nbox=7, seed=1), maxc=128, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
 st = torch.zeros(B * 16, dtype=torch.int64, device="cuda")
 E.be.lib.dss_diag_set_lcp_stamps(ctypes.c_void_p(st.data_ptr()), E.be.stream())
 E.step(); torch.cuda.synchronize()
