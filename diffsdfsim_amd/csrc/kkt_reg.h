@@ -54,6 +54,26 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 #endif
 }
+// min / max of a double over the wavefront with the same DPP ladder (exact, order-independent); ~6x shorter
+// dependent chain than six ds_bpermute shuffles, which matters with one wavefront per SIMD
+#if defined(DSS_EMU)
+__device__ __forceinline__ double wave_min_dpp(double v) { return wave_min(v); }
+__device__ __forceinline__ double wave_max_dpp(double v) { return wave_max(v); }
+#else
+#define DSS_DPP_D(OP, ctrl, rmask, bmask)                                                                          \
+    { const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, rmask, bmask, false); \
+      const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, rmask, bmask, false); \
+      v = OP(v, __hiloint2double(hi, lo)); }
+#define DSS_DPP_LADDER(OP)                                                                                         \
+    DSS_DPP_D(OP, 0x111, 0xf, 0xf) DSS_DPP_D(OP, 0x112, 0xf, 0xf) DSS_DPP_D(OP, 0x113, 0xf, 0xf)                   \
+    DSS_DPP_D(OP, 0x114, 0xf, 0xe) DSS_DPP_D(OP, 0x118, 0xf, 0xc) DSS_DPP_D(OP, 0x142, 0xa, 0xf)                   \
+    DSS_DPP_D(OP, 0x143, 0xc, 0xf)                                                                                 \
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+__device__ __forceinline__ double wave_min_dpp(double v) { DSS_DPP_LADDER(fmin) }
+__device__ __forceinline__ double wave_max_dpp(double v) { DSS_DPP_LADDER(fmax) }
+#undef DSS_DPP_LADDER
+#undef DSS_DPP_D
+#endif
 __device__ __forceinline__ int lane_of_step(int step, int k)
 {
     const unsigned long long m = __ballot(step == k);
@@ -107,13 +127,13 @@ template <int N> __device__ __forceinline__ void regk_factor(RegK<N> &R)
         if (lane == p) R.step = k;
         const double inv = 1.0 / wave_bcast(R.a[k], p);
         const bool upd = R.step == N;
-        const double l = R.a[k] * inv;
-        if (upd) R.a[k] = l;
+        const double l = upd ? R.a[k] * inv : 0.0;   // rows that already served as pivot take a zero multiplier:
+        if (upd) R.a[k] = l;                         // a - 0 * p == a exactly, and the update needs no select
         if (lane == p) R.a[k] = inv;
 #pragma unroll
         for (int j = k + 1; j < N; ++j) {
             const double pj = wave_bcast(R.a[j], p);
-            if (upd) R.a[j] -= l * pj;
+            R.a[j] -= l * pj;
         }
     }
 }

@@ -481,10 +481,10 @@ struct StepAcc {
     }
     __device__ inline double finish()
     {
-        const double mx = wave_max(amax), mn = wave_min(amin_keep);
-        const double anyp = wave_max((double)any_pos);
+        const double mx = wave_max_dpp(amax), mn = wave_min_dpp(amin_keep);
+        const bool anyp = __ballot(any_pos) != 0ull;
         const double repl = mx > 1.0 ? mx : 1.0;
-        return anyp > 0.0 ? fmin(mn, repl) : mn;
+        return anyp ? fmin(mn, repl) : mn;
     }
 };
 
@@ -584,8 +584,8 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
                 mins = fmin(mins, -u[q]);
             }
         }
-        mins = wave_min(mins);
-        minz = wave_min(minz);
+        mins = wave_min_dpp(mins);
+        minz = wave_min_dpp(minz);
         __syncthreads();
         for (int c = lane; c < nc; c += WAVE)
 #pragma unroll
