@@ -793,6 +793,310 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
     if (lane == 0) { iters[sc] = it; status[sc] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
 }
 
+// The same solver with the per-contact IPM state (s, z, rz, ds, dz, d = z/s) held in registers: lane l owns contacts
+// l and l + 64 (maxc <= 128), every loop over them is unrolled with compile-time indices.  Nothing but the contact
+// operands is re-read from memory inside the iteration, d is divided out once per iteration instead of once per
+// pass, and sum(s z) after the affine step needs no pass at all.  Arithmetic per contact is expression for
+// expression that of lcp_contact_forward_kernel (the streaming form, kept for maxc > 128): results are bit-identical.
+template <int ND>
+__global__ void __launch_bounds__(64)
+lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const double *A_, const double *bvec_,
+                               const double *cop_, const int *cbody_, const int *ncs, const int *active, int nb, int neq,
+                               int maxc, double eps, int not_improved_lim, int max_iter, double *x_out_, double *lam_,
+                               double *slack_, double *nu_, int *iters, int *status, double *ws_)
+{
+    constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF, CPL = 2;
+    DSS_DYN_LDS(double, ldsmem);
+    const int sc = blockIdx.x, lane = lane_id();
+    if (active && !active[sc]) return;
+    Lds L;
+    carve_lds(L, ldsmem, nb, neq, maxc);
+    const int nz = L.nz, n = L.n;
+    const double *Mblk = Mblk_ + (size_t)sc * nb * 36, *pvec = pvec_ + (size_t)sc * nz;
+    const double *A = neq ? A_ + (size_t)sc * neq * nz : nullptr, *bvec = neq ? bvec_ + (size_t)sc * neq : nullptr;
+    const double *cop = cop_ + (size_t)sc * NF * maxc;
+    const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
+    double *x_out = x_out_ + (size_t)sc * nz, *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
+    double *nu = neq ? nu_ + (size_t)sc * neq : nullptr;
+    L.kf = ws_ + (size_t)sc * (5 * NR * maxc + 64 * 64) + (size_t)5 * NR * maxc;
+    L.Ag = A;
+    int nc = ncs[sc];
+    if (nc > maxc) nc = maxc;
+    const int nineq = nc * NR;
+
+    double s[CPL][NR], z[CPL][NR], rzv[CPL][NR], dsv[CPL][NR], dzv[CPL][NR], av[CPL][NR];
+    bool valid[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) valid[r] = lane + WAVE * r < nc;
+
+    for (int i = lane; i < nz; i += WAVE) L.pl[i] = pvec[i];
+    for (int c = lane; c < nc; c += WAVE) {
+        const int o = 3 * (1 + ND);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) L.pbuf[6 * c + j] = cop[(size_t)(o + j) * maxc + c];
+    }
+    __syncthreads();
+    build_lists(L, cbody, nc);
+
+    // ---- initial point: d = 1  (batch.py:85-110) -------------------------------------------
+    {
+        double w0[CPL][3];
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const int c = lane + WAVE * r;
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double a[NR], t[NR], u[NR], C[9];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { a[q] = 1.0; t[q] = 0.0; }
+            t[0] = -g.hn;  // rz - rs/d with rz = -h, rs = 0
+            w_apply<ND>(g.mu, a, 1.0, t, u);
+            w_vec<ND>(g, u, w0[r]);
+            c_mat<ND>(g, a, 1.0, C);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) L.cw[9 * c + j] = C[j];
+        }
+        __syncthreads();
+        assemble_K(L, Mblk, A, cbody, nc);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r)
+            if (valid[r])
+#pragma unroll
+                for (int j = 0; j < 3; ++j) L.cw[3 * (lane + WAVE * r) + j] = w0[r][j];
+        __syncthreads();
+    }
+    gather<1>(L, L.g1, nullptr);
+    {
+        double rhs = 0.0;
+        if (lane < nz) rhs = -L.pl[lane] - L.g1[lane];
+        else if (lane < n) rhs = bvec[lane - nz];
+        const double sol = kkt_factor_solve(L, rhs);
+        if (lane < n) L.xv[lane] = sol;
+    }
+    __syncthreads();
+    if (nc == 0) {  // no complementarity conditions: the linear solve is the answer (engines.py:40-54)
+        if (lane < nz) x_out[lane] = L.xv[lane];
+        else if (lane < n) nu[lane - nz] = L.xv[lane];
+        if (lane == 0) { iters[sc] = 0; status[sc] = DSS_LCP_OK; }
+        return;
+    }
+    {
+        double mins = INFINITY, minz = INFINITY;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, lane + WAVE * r);
+            double a[NR], rr[NR], u[NR], vr[3];
+            rel_vel<ND>(L.xv, g, vr);
+            g_rows<ND>(g, vr, rr);
+            rr[0] -= g.hn;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) a[q] = 1.0;
+            w_apply<ND>(g.mu, a, 1.0, rr, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                z[r][q] = u[q];
+                s[r][q] = -u[q];
+                minz = fmin(minz, u[q]);
+                mins = fmin(mins, -u[q]);
+            }
+        }
+        mins = wave_min_dpp(mins);
+        minz = wave_min_dpp(minz);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                if (mins < 0) s[r][q] -= mins - 1.0;
+                if (minz < 0) z[r][q] -= minz - 1.0;
+            }
+    }
+
+    double best = 0.0;
+    int have_best = 0, not_improved = 0, it = 0;
+    for (it = 0; it < max_iter; ++it) {
+        // ---- residuals (batch.py:117-131), the affine right-hand side and K(d) ------------------
+        double acc_rz = 0.0, acc_sz = 0.0, Cv[CPL][9];
+        const int l0 = opaque_lane(lane);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const int c = l0 + WAVE * r;
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double gx[NR], fz[NR], t[NR], u[NR], vr[3], w[3];
+            rel_vel<ND>(L.xv, g, vr);
+            g_rows<ND>(g, vr, gx);
+            f_rows<ND>(g.mu, z[r], fz);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double rz = gx[q] + s[r][q] - (q == 0 ? g.hn : 0.0) - fz[q];
+                rzv[r][q] = rz;
+                acc_rz += rz * rz;
+                acc_sz += s[r][q] * z[r][q];
+                av[r][q] = z[r][q] / s[r][q];   // 1/a = d
+                t[q] = rz - s[r][q];            // rz - rs/d with rs = z
+            }
+            w_vec<ND>(g, z[r], w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[6 * c + j] = w[j];
+            const double ag = s[r][NR - 1] / z[r][NR - 1];
+            w_apply<ND>(g.mu, av[r], ag, t, u);
+            w_vec<ND>(g, u, w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[6 * c + 3 + j] = w[j];
+            c_mat<ND>(g, av[r], ag, Cv[r]);
+        }
+        acc_rz = wave_sum(acc_rz);
+        const double sz = wave_sum(acc_sz);
+        __syncthreads();
+        gather<2>(L, L.g1, L.g2);  // g1 = G^T z, g2 = G^T W (rz - s)
+        double rx = 0.0, ry = 0.0;
+        if (lane < nz) {
+            rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane];
+            for (int e = 0; e < neq; ++e) rx += A[e * nz + lane] * L.xv[nz + e];
+        } else if (lane < n) {
+            const int e = lane - nz;
+            for (int j = 0; j < nz; ++j) ry += A[e * nz + j] * L.xv[j];
+            ry -= bvec[e];
+        }
+        const double nrx = sqrt(wave_sum(rx * rx)), nry = sqrt(wave_sum(ry * ry));
+        const double mu = fabs(sz / nineq);
+        const double resid = sqrt(acc_rz) + nry + nrx + nineq * mu;
+        if (!have_best || resid < best) {
+            best = resid; have_best = 1; not_improved = 0;
+            if (lane < nz) x_out[lane] = L.xv[lane];
+            else if (lane < n) nu[lane - nz] = L.xv[lane];
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+                if (valid[r])
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        lam[(size_t)q * maxc + l0 + WAVE * r] = z[r][q];
+                        slack[(size_t)q * maxc + l0 + WAVE * r] = s[r][q];
+                    }
+        } else {
+            ++not_improved;
+        }
+        if (not_improved == not_improved_lim || best < eps || mu > 1e32) break;
+
+        // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CPL; ++r)
+            if (valid[r])
+#pragma unroll
+                for (int j = 0; j < 9; ++j) L.cw[9 * (l0 + WAVE * r) + j] = Cv[r][j];
+        __syncthreads();
+        assemble_K(L, Mblk, A, cbody, nc);
+        {
+            double rhs = 0.0;
+            if (lane < nz) rhs = -rx - L.g2[lane];
+            else if (lane < n) rhs = -ry;
+            const double sol = kkt_factor_solve(L, rhs);
+            if (lane < n) L.dxa[lane] = sol;
+        }
+        __syncthreads();
+        StepAcc stz, sts;
+        const int l1 = opaque_lane(lane);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, l1 + WAVE * r);
+            double rr[NR], u[NR], vr[3];
+            rel_vel<ND>(L.dxa, g, vr);
+            g_rows<ND>(g, vr, rr);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) rr[q] += rzv[r][q] - s[r][q];
+            w_apply<ND>(g.mu, av[r], s[r][NR - 1] / z[r][NR - 1], rr, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double dz = u[q], ds = (-z[r][q] - dz) / av[r][q];
+                dzv[r][q] = dz;
+                dsv[r][q] = ds;
+                stz.add(z[r][q], dz);
+                sts.add(s[r][q], ds);
+            }
+        }
+        double alpha = fmin(fmin(stz.finish(), sts.finish()), 1.0);
+        double t3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r)
+            if (valid[r])
+#pragma unroll
+                for (int q = 0; q < NR; ++q) t3 += (s[r][q] + alpha * dsv[r][q]) * (z[r][q] + alpha * dzv[r][q]);
+        t3 = wave_sum(t3);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // ---- corrector (batch.py:194-205): rx = rz = ry = 0, rs = (-mu sig + ds dz)/s ----------
+        const int l2 = opaque_lane(lane);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const int c = l2 + WAVE * r;
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, c);
+            double t[NR], u[NR], w[3];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double rs2 = (-mu * sig + dsv[r][q] * dzv[r][q]) / s[r][q];
+                rzv[r][q] = rs2;                 // rz is not needed any more this iteration
+                t[q] = rs2 / av[r][q];
+            }
+            w_apply<ND>(g.mu, av[r], s[r][NR - 1] / z[r][NR - 1], t, u);
+            w_vec<ND>(g, u, w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = w[j];
+        }
+        __syncthreads();
+        gather<1>(L, L.g1, nullptr);
+        {
+            double rhs = (lane < nz) ? L.g1[lane] : 0.0;
+            const double sol = kkt_solve(L, rhs);
+            if (lane < n) L.sol[lane] = sol;
+        }
+        __syncthreads();
+        StepAcc stz2, sts2;
+        const int l3 = opaque_lane(lane);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            if (!valid[r]) continue;
+            Geo<ND> g;
+            load_geo<ND>(g, cop, cbody, maxc, l3 + WAVE * r);
+            double rr[NR], u[NR], vr[3];
+            rel_vel<ND>(L.sol, g, vr);
+            g_rows<ND>(g, vr, rr);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) rr[q] -= rzv[r][q] / av[r][q];
+            w_apply<ND>(g.mu, av[r], s[r][NR - 1] / z[r][NR - 1], rr, u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const double dz = dzv[r][q] + u[q];
+                const double ds = dsv[r][q] + (-rzv[r][q] - u[q]) / av[r][q];
+                dzv[r][q] = dz;
+                dsv[r][q] = ds;
+                stz2.add(z[r][q], dz);
+                sts2.add(s[r][q], ds);
+            }
+        }
+        alpha = fmin(0.999 * fmin(stz2.finish(), sts2.finish()), 1.0);
+        __syncthreads();
+        if (lane < n) L.xv[lane] += alpha * (L.dxa[lane] + L.sol[lane]);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                s[r][q] += alpha * dsv[r][q];
+                z[r][q] += alpha * dzv[r][q];
+            }
+        __syncthreads();
+    }
+    if (lane == 0) { iters[sc] = it; status[sc] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
+}
+
 // Implicit backward (lcp.py:156-213) in the same reduced form; gradients come out already
 // contracted onto the contact operands (directions, contact points, mu, h_n), the mass blocks
 // and the linear term -- the dense dG / dF of the reference are never formed.
@@ -948,7 +1252,16 @@ int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double
     if (workspace_bytes < dss_lcp_contact_workspace_bytes(B, nb, neq, maxc, fric_dirs)) return DSS_E_WORKSPACE;
     const size_t lds = lds_bytes(nb, neq, maxc);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
-    if (fric_dirs == 8)
+    if (maxc <= 128) {   // two contacts per lane: IPM state in registers
+        if (fric_dirs == 8)
+            hipLaunchKernelGGL(lcp_contact_forward_reg_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A,
+                               bvec, cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu,
+                               iters, status, (double *)workspace);
+        else
+            hipLaunchKernelGGL(lcp_contact_forward_reg_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A,
+                               bvec, cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu,
+                               iters, status, (double *)workspace);
+    } else if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_forward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
                            cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
                            status, (double *)workspace);

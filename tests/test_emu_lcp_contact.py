@@ -10,7 +10,8 @@ from oracle import lcp_oracle as O
 
 @pytest.mark.parametrize("cfg", [dict(seed=1, B=3, nb=2, maxc=8, fd=8), dict(seed=2, B=2, nb=4, maxc=16, fd=8),
                                  dict(seed=3, B=2, nb=3, maxc=8, fd=4), dict(seed=4, B=1, nb=3, maxc=80, fd=8, nc_lo=70),
-                                 dict(seed=6, B=2, nb=8, maxc=24, fd=8, nc_lo=10)])
+                                 dict(seed=6, B=2, nb=8, maxc=24, fd=8, nc_lo=10),
+                                 dict(seed=7, B=1, nb=3, maxc=136, fd=8, nc_lo=100)])   # > 128: the streaming kernel
 def test_contact_lcp_forward_backward_vs_dense_oracle(cfg):
     P = S.random_problem(**cfg)
     x, lam, slack, nu, it, st = emu.lcp_contact_forward(P, max_iter=10)

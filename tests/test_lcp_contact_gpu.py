@@ -31,7 +31,8 @@ def run(P, max_iter=10):
 
 @pytest.mark.parametrize("cfg", [dict(seed=11, B=6, nb=2, maxc=8, fd=8), dict(seed=12, B=4, nb=8, maxc=32, fd=8),
                                  dict(seed=13, B=3, nb=3, maxc=8, fd=4), dict(seed=14, B=2, nb=4, maxc=96, fd=8, nc_lo=70),
-                                 dict(seed=15, B=5, nb=2, maxc=8, fd=8), dict(seed=16, B=3, nb=8, maxc=24, fd=8, nc_lo=10)])
+                                 dict(seed=15, B=5, nb=2, maxc=8, fd=8), dict(seed=16, B=3, nb=8, maxc=24, fd=8, nc_lo=10),
+                                 dict(seed=17, B=2, nb=3, maxc=136, fd=8, nc_lo=100)])   # > 128: the streaming kernel
 def test_forward_backward_vs_dense_oracle(cfg):
     from diffsdfsim_amd.lcp.contact import lcp_contact_backward
     from oracle import lcp_oracle as O
