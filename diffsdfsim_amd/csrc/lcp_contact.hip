@@ -321,36 +321,43 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
 #pragma unroll
             for (int j = 0; j < 3; ++j) o[j] = kind == 0 ? x[j] : a[j];
         };
+        // batches of BATCH contacts regardless of where the (body1, body2) runs end; the run sum is flushed into K
+        // whenever the pair changes (uniform branch), so the accumulation order stays the contact order
+        constexpr int BATCH = 8;
+        int pb1 = -1, pb2 = -1;
+        double acc[3] = {0.0, 0.0, 0.0};
+        auto flush = [&]() {
+            if (pb1 < 0) return;
+            const int row = 6 * (br ? pb2 : pb1) + rr, col = 6 * (bc ? pb2 : pb1) + 3 * kind;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { L.K[row * lda + col + j] += sgn * acc[j]; acc[j] = 0.0; }
+        };
         int c = 0;
-        while (c < nc) {
-            const int b1 = cbody[c], b2 = cbody[L.maxc + c];
-            int e = c + 1;
-            while (e < nc && cbody[e] == b1 && cbody[L.maxc + e] == b2) ++e;
-            double acc[3] = {0.0, 0.0, 0.0};
-            for (; c + 4 <= e; c += 4) {
-                Rd t[4];
-                double o[4][3];
+        for (; c + BATCH <= nc; c += BATCH) {
+            Rd t[BATCH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rd(c + u, t[u]);
+            for (int u = 0; u < BATCH; ++u) rd(c + u, t[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) term(t[u], o[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[j] += o[u][j];
-            }
-            for (; c < e; ++c) {
-                Rd t;
+            for (int u = 0; u < BATCH; ++u) {
+                const int b1 = cbody[c + u], b2 = cbody[L.maxc + c + u];
+                if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
                 double o[3];
-                rd(c, t);
-                term(t, o);
+                term(t[u], o);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[j] += o[j];
             }
-            const int row = 6 * (br ? b2 : b1) + rr, col = 6 * (bc ? b2 : b1) + 3 * kind;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) L.K[row * lda + col + j] += sgn * acc[j];
         }
+        for (; c < nc; ++c) {
+            const int b1 = cbody[c], b2 = cbody[L.maxc + c];
+            if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
+            Rd t;
+            double o[3];
+            rd(c, t);
+            term(t, o);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] += o[j];
+        }
+        flush();
     }
     __syncthreads();
 }
@@ -425,13 +432,11 @@ template <int N> __device__ double kkt_factor_solve_reg(Lds &L, double rhs)
         else if (lane < N) v = (j < nz) ? L.Ag[(lane - nz) * nz + j] : 0.0;
         R.a[j] = v;
     }
-    R.step = N;
-    regk_factor<N>(R);
-    const double x = regk_solve<N>(R, rhs);
+    regk_factor_natural<N>(R);
+    const double x = regk_solve_natural<N>(R, rhs);
     if (L.kf) {   // the forward pass solves a second time with the same factors (corrector)
 #pragma unroll
         for (int j = 0; j < N; ++j) L.kf[(size_t)j * WAVE + lane] = R.a[j];
-        if (lane < N) L.piv[lane] = R.step;
     }
     __syncthreads();
     return x;
@@ -442,8 +447,7 @@ template <int N> __device__ double kkt_solve_reg(Lds &L, double rhs)
     const int lane = lane_id();
 #pragma unroll
     for (int j = 0; j < N; ++j) R.a[j] = L.kf[(size_t)j * WAVE + lane];
-    R.step = lane < N ? L.piv[lane] : -1;
-    return regk_solve<N>(R, rhs);
+    return regk_solve_natural<N>(R, rhs);
 }
 __device__ double kkt_factor_solve(Lds &L, double rhs)
 {
@@ -1216,14 +1220,6 @@ inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
 }  // namespace
 
 #if defined(DSS_DIAG)
-__global__ void selftest_wave_max_kernel(const unsigned *in, unsigned *out)
-{
-    out[blockIdx.x] = dss::wave_max_u32(in[blockIdx.x * 64 + threadIdx.x]);
-}
-extern "C" void dss_diag_wave_max(const unsigned *in, unsigned *out, int n, void *stream)
-{
-    hipLaunchKernelGGL(selftest_wave_max_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, in, out);
-}
 __global__ void set_lcp_stamps_kernel(long long *p) { g_lcp_stamps = p; }
 extern "C" void dss_diag_set_lcp_stamps(long long *p, void *stream)
 {
