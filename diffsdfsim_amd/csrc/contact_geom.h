@@ -33,9 +33,13 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
 // One contact from a barycentric point on a triangle of body 1's mesh.
 //   tri: the three vertices (body-1 frame), abc: barycentrics (constants)
 //   out: n (world), p1, p2 (world-frame offsets from the body origins), pen = -phi_2
+//   stable_io: < 0 on entry = decide which body's normal is used from the two Laplacian probes and report it (0/1);
+//              >= 0 = use that decision (the backward's derivative passes re-use the one of their value pass: the
+//              probes carry no gradient and cost twelve SDF evaluations)
 template <class T>
 __host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const BodyG<T> &b2, const T tri[3][3],
-                                                  const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen)
+                                                  const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen,
+                                                  int *stable_io = nullptr)
 {
     T cp1[3], d1, n1[3], cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
     for (int i = 0; i < 3; ++i) cp1[i] = tri[0][i] * abc[0] + tri[1][i] * abc[1] + tri[2][i] * abc[2];
@@ -47,8 +51,13 @@ __host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const Body
     for (int i = 0; i < 3; ++i) { cpw[i] = p1[i] + b1.pos[i]; rel[i] = cpw[i] - b2.pos[i]; }
     quat_apply_inv(b2.q, rel, cp2);
     query_sdf(b2.shape, cp2, d2, n2, true);
-    const double l1 = lap_probe(b1.shape, cp1, val(d1), lap_h), l2 = lap_probe(b2.shape, cp2, val(d2), lap_h);
-    const bool stable = fabs(l2) < fabs(l1);
+    bool stable;
+    if (stable_io && *stable_io >= 0) stable = *stable_io != 0;
+    else {
+        const double l1 = lap_probe(b1.shape, cp1, val(d1), lap_h), l2 = lap_probe(b2.shape, cp2, val(d2), lap_h);
+        stable = fabs(l2) < fabs(l1);
+        if (stable_io) *stable_io = stable ? 1 : 0;
+    }
     if (stable) {
         quat_apply(b2.q, n2, n);
     } else {

@@ -70,10 +70,19 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     const int mesh = W.mesh_id[(size_t)sc * nb + b1];
     const int voff = W.mesh_voff[mesh], foff = W.mesh_foff[mesh];
     const int *fv = W.faces + (size_t)(foff + face) * 3;
+    int stable = -1;   // decided by the first pass (values are the same in all five), re-used by the others
+    // unrolled: with the group known at compile time the seeds are constants, and (with the finite-math flags this
+    // file is built with, _lib.PER_FILE_FLAGS) the arithmetic on derivative slots that stay zero folds away
+#pragma unroll
     for (int grp = 0; grp < 5; ++grp) {
         BodyG<D> B1, B2;
         D pr1[3], pr2[3];
-        auto seed = [&](int t, double v) { D d(v); const int s = t - N * grp; if (s >= 0 && s < N) d.d[s] = 1.0; return d; };
+        auto seed = [&](int t, double v) {
+            D d(v);
+#pragma unroll
+            for (int sl = 0; sl < N; ++sl) if (sl == t - N * grp) d.d[sl] = 1.0;
+            return d;
+        };
         for (int i = 0; i < 4; ++i) { B1.q[i] = seed(i, P1[i]); B2.q[i] = seed(7 + i, P2[i]); }
         for (int i = 0; i < 3; ++i) {
             B1.pos[i] = seed(4 + i, P1[4 + i]); B2.pos[i] = seed(11 + i, P2[4 + i]);
@@ -88,11 +97,12 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
                 D d(val0);
                 // box: own axis; sphere: radius; cylinder: x,y <- rad, z <- height
                 const int t = (ty1 == SHAPE_BOX) ? 14 + i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 15 : 14), s = t - N * grp;
-                if (s >= 0 && s < N) d.d[s] = gr;
+#pragma unroll
+                for (int sl = 0; sl < N; ++sl) if (sl == s) d.d[sl] = gr;   // selects: a run-time index would put d in scratch
                 tri[v][i] = d;
             }
         D n[3], p1[3], p2[3], pen;
-        contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen);
+        contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable);
         for (int s = 0; s < N; ++s) {
             double acc = 0.0;
             for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + gbar[3 + i] * p1[i].d[s] + gbar[6 + i] * p2[i].d[s];
@@ -192,7 +202,11 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
             for (int grp = 0; grp < 11; ++grp) {
                 typedef Dual<4> D;
                 D di[43];
-                for (int i = 0; i < 43; ++i) { di[i] = D(in[i]); const int sl = i - 4 * grp; if (sl >= 0 && sl < 4) di[i].d[sl] = 1.0; }
+                for (int i = 0; i < 43; ++i) {
+                    di[i] = D(in[i]);
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) if (sl == i - 4 * grp) di[i].d[sl] = 1.0;
+                }
                 const D r = toc_D(di);
                 for (int sl = 0; sl < 4; ++sl) outg[4 * grp + sl] = wgt * r.d[sl];
             }
