@@ -499,12 +499,17 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         }
         for (int i = 0; i < 3; ++i) x[i] /= 3.0;
         double phi, g[3], rad = 0.0;
-        query_sdf(Bd.g.shape, x, phi, g, true);
+        // the reference also asks for |grad phi| > 1e-12.  The box gradient is a unit vector wherever the query cube
+        // is hit (outside: normalised max(q,0); inside/on the surface: the failsafe direction has norm >= 1) and zero
+        // outside the cube, so for boxes that test is the cube test and the gradient need not be evaluated.
+        const bool box = Bd.g.shape.type == SHAPE_BOX;
+        const bool in_cube = query_sdf(Bd.g.shape, x, phi, g, !box);
         for (int k = 0; k < 3; ++k) {
             const double d[3] = {x[0] - pqr[k][0], x[1] - pqr[k][1], x[2] - pqr[k][2]};
             const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             if (r > rad) rad = r;
         }
+        if (box) return (phi < rad + W.eps) && in_cube;
         const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
@@ -927,34 +932,56 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
 }
 
 // ---- gather the per-pair lists into the scene's contact list in callback order ------------------
+// Callback order = undirected pairs (i < j) ascending, i->j before j->i.  The counts of all ordered slots are read
+// in one round, a wavefront scan gives their offsets, and every output contact finds its slot by bisection in LDS
+// (instead of walking the nb (nb - 1) slots one dependent global load after the other).
 __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *nc_out, int *body_out, int *face_out,
                                                                double *abc_out, double *geom_out)
 {
-    const int sc = blockIdx.x, lane = threadIdx.x, np = npairs_of(W.nb), MP = W.max_pc, MX = W.maxc;
+    constexpr int MAXSLOT = 64 * 63;
+    __shared__ int s_off[MAXSLOT + 1];
+    __shared__ short s_a[MAXSLOT], s_b[MAXSLOT];
+    const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, np = npairs_of(nb), MP = W.max_pc, MX = W.maxc;
     if (!W.active[sc]) return;
-    int off = 0;
-    for (int i = 0; i < W.nb; ++i)
-        for (int j = i + 1; j < W.nb; ++j)
-            for (int dir = 0; dir < 2; ++dir) {
-                const int a = dir ? j : i, b = dir ? i : j;
-                const int dp = a * (W.nb - 1) + (b < a ? b : b - 1);
-                const int cnt = W.pc_count[(size_t)sc * np + dp];
-                const int *pf = W.pc_face + ((size_t)sc * np + dp) * MP;
-                const double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
-                for (int k = lane; k < cnt; k += 64) {
-                    const int o = off + k;
-                    if (o >= MX) continue;
-                    body_out[(size_t)sc * 2 * MX + o] = a;
-                    body_out[(size_t)sc * 2 * MX + MX + o] = b;
-                    face_out[(size_t)sc * MX + o] = pf[k];
-                    for (int f = 0; f < 3; ++f) abc_out[((size_t)sc * 3 + f) * MX + o] = pabc[(size_t)f * MP + k];
-                    for (int f = 0; f < 10; ++f) geom_out[((size_t)sc * 10 + f) * MX + o] = pg[(size_t)f * MP + k];
-                }
-                off += cnt;
-            }
+    int run = 0;
+    for (int base = 0; base < np; base += 64) {
+        const int slot = base + lane;
+        int cnt = 0, a = 0, b = 0;
+        if (slot < np) {
+            int i = 0, rem = slot >> 1;
+            while (rem >= nb - 1 - i) { rem -= nb - 1 - i; ++i; }
+            const int j = i + 1 + rem;
+            a = (slot & 1) ? j : i; b = (slot & 1) ? i : j;
+            cnt = W.pc_count[(size_t)sc * np + a * (nb - 1) + (b < a ? b : b - 1)];
+        }
+        int incl = cnt;   // inclusive scan over the wavefront
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (slot < np) { s_off[slot] = run + incl - cnt; s_a[slot] = (short)a; s_b[slot] = (short)b; }
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) s_off[np] = run;
+    __syncthreads();
+    const int total = run < MX ? run : MX;
+    for (int o = lane; o < total; o += 64) {
+        int lo = 0, hi = np;   // last slot with s_off[slot] <= o
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= o) lo = mid; else hi = mid; }
+        const int a = s_a[lo], b = s_b[lo], k = o - s_off[lo];
+        const size_t dp = (size_t)sc * np + a * (nb - 1) + (b < a ? b : b - 1);
+        const int *pf = W.pc_face + dp * MP;
+        const double *pabc = W.pc_abc + dp * 3 * MP, *pg = W.pc_geom + dp * 10 * MP;
+        const int face = pf[k];   // loads first, stores after (no load has to wait behind a possibly aliasing store)
+        double abc[3], geo[10];
+        for (int f = 0; f < 3; ++f) abc[f] = pabc[(size_t)f * MP + k];
+        for (int f = 0; f < 10; ++f) geo[f] = pg[(size_t)f * MP + k];
+        body_out[(size_t)sc * 2 * MX + o] = a;
+        body_out[(size_t)sc * 2 * MX + MX + o] = b;
+        face_out[(size_t)sc * MX + o] = face;
+        for (int f = 0; f < 3; ++f) abc_out[((size_t)sc * 3 + f) * MX + o] = abc[f];
+        for (int f = 0; f < 10; ++f) geom_out[((size_t)sc * 10 + f) * MX + o] = geo[f];
+    }
     if (lane == 0) {
-        if (off > MX) { atomicOr(W.overflow + sc, 8); off = MX; }
-        nc_out[sc] = off;
+        if (run > MX) atomicOr(W.overflow + sc, 8);
+        nc_out[sc] = total;
     }
 }
 

@@ -120,18 +120,23 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
     const bool accept = !W.invalid[sc] || tiny;
     if (accept) {
         const int nc_new = N.nc[sc], nc_old = W.nc[sc];
-        // toc_contacts: contacts between bodies that had no contact at the start (world.py:272-274)
+        // toc_contacts: contacts between bodies that had no contact at the start (world.py:272-274).  The body pairs
+        // of the old contacts go into an LDS bitmap, which the new contacts then look up.
+        __shared__ unsigned s_pairs[64 * 64 / 32];
+        for (int w = lane; w < (nb * nb + 31) / 32; w += 64) s_pairs[w] = 0u;
+        __syncthreads();
+        for (int c = lane; c < nc_old; c += 64) {
+            const int bit = W.c_body[(size_t)sc * 2 * MX + c] * nb + W.c_body[(size_t)sc * 2 * MX + MX + c];
+            atomicOr(&s_pairs[bit >> 5], 1u << (bit & 31));
+        }
+        __syncthreads();
         int toc = 0;
         for (int c = lane; c < nc_new; c += 64) {
             const int a = N.body[(size_t)sc * 2 * MX + c], b = N.body[(size_t)sc * 2 * MX + MX + c];
-            int seen = 0;
-            for (int k = 0; k < nc_old && !seen; ++k) {
-                const int a0 = W.c_body[(size_t)sc * 2 * MX + k], b0 = W.c_body[(size_t)sc * 2 * MX + MX + k];
-                seen = (a0 == a && b0 == b) || (a0 == b && b0 == a);
-            }
-            toc |= !seen;
+            const int ab = a * nb + b, ba = b * nb + a;
+            toc |= !(((s_pairs[ab >> 5] >> (ab & 31)) | (s_pairs[ba >> 5] >> (ba & 31))) & 1u);
         }
-        toc = (int)wave_max((double)toc);
+        toc = __ballot(toc) != 0ull;
         // tape record of the accepted sub-step
         const int slot = W.nsub[sc];
         if (W.tp_pose && slot < W.max_sub) {
@@ -145,16 +150,25 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
             }
             if (lane < W.neq) W.tp_nu[rec * W.neq + lane] = W.nu[(size_t)sc * W.neq + lane];
             const int NR = W.fric_dirs + 2;
+            // all loads of a contact first, then all stores: the compiler may not move a load across a store through
+            // these (possibly aliasing) pointers, and a load-store-load chain costs one memory round trip per field
             for (int c = lane; c < nc_old; c += 64) {
-                W.tp_body[rec * 2 * MX + c] = W.c_body[(size_t)sc * 2 * MX + c];
-                W.tp_body[rec * 2 * MX + MX + c] = W.c_body[(size_t)sc * 2 * MX + MX + c];
-                W.tp_face[rec * MX + c] = W.c_face[(size_t)sc * MX + c];
-                for (int f = 0; f < 3; ++f) W.tp_abc[(rec * 3 + f) * MX + c] = W.c_abc[((size_t)sc * 3 + f) * MX + c];
-                for (int f = 0; f < 10; ++f) W.tp_geom[(rec * 10 + f) * MX + c] = W.c_geom[((size_t)sc * 10 + f) * MX + c];
-                for (int q = 0; q < NR; ++q) {
-                    W.tp_lam[(rec * NR + q) * MX + c] = W.lam[((size_t)sc * NR + q) * MX + c];
-                    W.tp_slack[(rec * NR + q) * MX + c] = W.slack[((size_t)sc * NR + q) * MX + c];
-                }
+                const int b1 = W.c_body[(size_t)sc * 2 * MX + c], b2 = W.c_body[(size_t)sc * 2 * MX + MX + c];
+                const int face = W.c_face[(size_t)sc * MX + c];
+                double abc[3], geo[10], lm[10], sl[10];
+                for (int f = 0; f < 3; ++f) abc[f] = W.c_abc[((size_t)sc * 3 + f) * MX + c];
+                for (int f = 0; f < 10; ++f) geo[f] = W.c_geom[((size_t)sc * 10 + f) * MX + c];
+#pragma unroll
+                for (int q = 0; q < 10; ++q)
+                    if (q < NR) { lm[q] = W.lam[((size_t)sc * NR + q) * MX + c]; sl[q] = W.slack[((size_t)sc * NR + q) * MX + c]; }
+                W.tp_body[rec * 2 * MX + c] = b1;
+                W.tp_body[rec * 2 * MX + MX + c] = b2;
+                W.tp_face[rec * MX + c] = face;
+                for (int f = 0; f < 3; ++f) W.tp_abc[(rec * 3 + f) * MX + c] = abc[f];
+                for (int f = 0; f < 10; ++f) W.tp_geom[(rec * 10 + f) * MX + c] = geo[f];
+#pragma unroll
+                for (int q = 0; q < 10; ++q)
+                    if (q < NR) { W.tp_lam[(rec * NR + q) * MX + c] = lm[q]; W.tp_slack[(rec * NR + q) * MX + c] = sl[q]; }
             }
             if (lane == 0) {
                 W.tp_dt[rec] = W.dt_use[sc]; W.tp_nc[rec] = nc_old;
@@ -164,11 +178,15 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
         __syncthreads();
         // commit the new contacts
         for (int c = lane; c < nc_new; c += 64) {
-            W.c_body[(size_t)sc * 2 * MX + c] = N.body[(size_t)sc * 2 * MX + c];
-            W.c_body[(size_t)sc * 2 * MX + MX + c] = N.body[(size_t)sc * 2 * MX + MX + c];
-            W.c_face[(size_t)sc * MX + c] = N.face[(size_t)sc * MX + c];
-            for (int f = 0; f < 3; ++f) W.c_abc[((size_t)sc * 3 + f) * MX + c] = N.abc[((size_t)sc * 3 + f) * MX + c];
-            for (int f = 0; f < 10; ++f) W.c_geom[((size_t)sc * 10 + f) * MX + c] = N.geom[((size_t)sc * 10 + f) * MX + c];
+            const int b1 = N.body[(size_t)sc * 2 * MX + c], b2 = N.body[(size_t)sc * 2 * MX + MX + c], face = N.face[(size_t)sc * MX + c];
+            double abc[3], geo[10];
+            for (int f = 0; f < 3; ++f) abc[f] = N.abc[((size_t)sc * 3 + f) * MX + c];
+            for (int f = 0; f < 10; ++f) geo[f] = N.geom[((size_t)sc * 10 + f) * MX + c];
+            W.c_body[(size_t)sc * 2 * MX + c] = b1;
+            W.c_body[(size_t)sc * 2 * MX + MX + c] = b2;
+            W.c_face[(size_t)sc * MX + c] = face;
+            for (int f = 0; f < 3; ++f) W.c_abc[((size_t)sc * 3 + f) * MX + c] = abc[f];
+            for (int f = 0; f < 10; ++f) W.c_geom[((size_t)sc * 10 + f) * MX + c] = geo[f];
         }
         if (lane == 0) {
             W.nc[sc] = nc_new;

@@ -136,6 +136,11 @@ template <class T> inline T shfl_from(T v, int src)
 inline void __syncthreads() { dss_emu::yield(); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return dss_emu::shfl_from(v, (dss_emu::st().cur & 63) ^ mask); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return dss_emu::shfl_from(v, src); }
+template <class T> inline T __shfl_up(T v, int d, int = 64)
+{
+    int l = dss_emu::st().cur & 63;
+    return dss_emu::shfl_from(v, l - d >= 0 ? l - d : l);
+}
 template <class T> inline T __shfl_down(T v, int d, int = 64)
 {
     int l = dss_emu::st().cur & 63;
@@ -177,6 +182,7 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
+inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
 // v_mfma_f64_16x16x4_f64 as documented for gfx950 (cdna_hip_programming.md section 3): lane l supplies
