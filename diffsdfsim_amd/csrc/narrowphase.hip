@@ -456,9 +456,13 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     load_body(W, sc, b, Bd);
     const int MC = W.max_cand;
     // candidate scratch belongs to the resident group, not to the item: it is reused item after item and stays in L2
-    int *cface = W.cand_face + (size_t)slot_id * 2 * MC, *kface = cface + MC;
-    int *cstate = W.cand_state + (size_t)slot_id * MC;
-    double *cb = W.cand_buf + (size_t)slot_id * DSS_CAND_FIELDS * MC;
+    int *__restrict__ cface = W.cand_face + (size_t)slot_id * 2 * MC, *__restrict__ kface = cface + MC;
+    int *__restrict__ cstate = W.cand_state + (size_t)slot_id * MC;
+    double *__restrict__ cb = W.cand_buf + (size_t)slot_id * DSS_CAND_FIELDS * MC;
+    // the mesh table is read-only and disjoint from every scratch array: tell the compiler, so that its loads are
+    // not serialised behind the scratch stores
+    const double *__restrict__ m_verts = W.verts, *__restrict__ m_fcent = W.fcent;
+    const int *__restrict__ m_faces = W.faces;
 #define CB(f, k) cb[(size_t)(f) * MC + (k)]
     const double sB = Bd.g.shape.scale;
 
@@ -491,13 +495,13 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     };
     // the reference's candidate test (contacts.py:44-52) in its own order of operations
     auto full_face = [&](int f, double pqr[3][3]) -> int {
-        const int *fv = W.faces + (size_t)(A.foff + f) * 3;
+        const int *fv = m_faces + (size_t)(A.foff + f) * 3;
         double x[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) {
-            to_frame(A.g, Bd.g, W.verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
+            to_frame(A.g, Bd.g, m_verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
             for (int i = 0; i < 3; ++i) x[i] += pqr[k][i];
         }
-        for (int i = 0; i < 3; ++i) x[i] /= 3.0;
+        div3(x, 3.0, x);   // the three exact quotients by one denominator (geom.h)
         double phi, g[3], rad = 0.0;
         // the reference also asks for |grad phi| > 1e-12.  The box gradient is a unit vector wherever the query cube
         // is hit (outside: normalised max(q,0); inside/on the surface: the failsafe direction has norm >= 1) and zero
@@ -514,7 +518,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
     auto test_face = [&](int f, double pqr[3][3]) -> int {
-        return cull_face(W.fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
+        return cull_face(m_fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
     };
     if (G::BT == 64 && nch <= G::CHCAP) {
         // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
@@ -550,7 +554,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             double c[4][3];
             for (int sub = 0; sub < 4; ++sub) {
                 const int f = f0 + 64 * sub < A.nf ? f0 + 64 * sub : A.nf - 1;
-                for (int d = 0; d < 3; ++d) c[sub][d] = W.fcent[(size_t)(A.foff + f) * 3 + d];
+                for (int d = 0; d < 3; ++d) c[sub][d] = m_fcent[(size_t)(A.foff + f) * 3 + d];
             }
             for (int sub = 0; sub < 4; ++sub) {
                 const int ok = f0 + 64 * sub < A.nf && cull_face(c[sub]);
@@ -764,11 +768,11 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         int flag = 0;
         double abc[3] = {0, 0, 0};
         if (k < ncand) {
-            const int *fv = W.faces + (size_t)(A.foff + cface[k]) * 3;
+            const int *fv = m_faces + (size_t)(A.foff + cface[k]) * 3;
             double xb1[3] = {0, 0, 0};
             for (int v = 0; v < 3; ++v) {
                 abc[v] = CB(12 + v, k);
-                const double *vp = W.verts + (size_t)(A.voff + fv[v]) * 3;
+                const double *vp = m_verts + (size_t)(A.voff + fv[v]) * 3;
                 for (int i = 0; i < 3; ++i) xb1[i] += vp[i] * abc[v];
             }
             double phi1, g1[3], gr[3], x[3], phi2, g2[3];
@@ -789,9 +793,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
     int bad = 0;
     for (int k = tid; k < ncon; k += G::BT) {
-        const int *fv = W.faces + (size_t)(A.foff + kface[k]) * 3;
+        const int *fv = m_faces + (size_t)(A.foff + kface[k]) * 3;
         double tri[3][3], n[3], p1[3], p2[3], pen;
-        for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = W.verts[(size_t)(A.voff + fv[v]) * 3 + i];
+        for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = m_verts[(size_t)(A.voff + fv[v]) * 3 + i];
         const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
         contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
         for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; CB(i, k) = p2[i]; }   // pqr (fields 0-8) is dead by now
