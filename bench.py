@@ -214,12 +214,15 @@ def main():
                 "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_ms": float(ms.mean()), "launches": len(ms),
                 "algorithmic_bytes_per_launch": algo, "note": note}
 
-    r_lcp = roof("lcp_contact_forward_kernel<4>", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
-                 "one wavefront per scene, KKT in registers/LDS: bound by serial fp64 latency, not HBM (DESIGN.md section 5)",
+    r_lcp = roof("lcp_contact_forward_reg_kernel<4>", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
+                 "one wavefront per scene and SIMD, KKT and IPM state in registers: bound by the serial fp64 issue latency "
+                 "of one wavefront, not by HBM; traffic above the algorithmic bytes is register spill around the "
+                 "factorisation (DESIGN.md section 5)",
                  traffic("lcp_contact_forward"))
     r_det = roof("narrowphase_kernel (+overlap_kernel, compact_contacts_kernel)", det_ms, detect_algorithmic_bytes(E),
-                 "Frank-Wolfe / SDF evaluation: bound by fp64 div/sqrt chains and block barriers, not HBM (DESIGN.md section 5)",
-                 traffic("narrowphase_kernel", "overlap_kernel"))
+                 "Frank-Wolfe / SDF evaluation: fp64 VALU bound (61 % VALU-busy, SQ_ACTIVE_INST_VALU; IEEE div/sqrt "
+                 "sequences), not HBM (DESIGN.md section 5)",
+                 traffic("narrowphase_kernel", "overlap_kernel", "compact_contacts"))
     dominant, other = (r_det, r_lcp) if det_ms.mean() >= lcp_ms.mean() else (r_lcp, r_det)
     res = {
         "metric": "sim steps/sec (fwd+bwd), 1024 batched 3D scenes x 8 SDF bodies",
