@@ -1,16 +1,17 @@
 """SDF rigid bodies of the 3-D layer (host-side mirror of sdf_physics/physics3d/bodies.py:402-1009).
 
 Same constructor arguments and attributes as the reference (``p``, ``pos``, ``rot``, ``v``, ``mass``, ``verts``,
-``faces``, ``dims``/``rad``, ``restitution``, ``fric_coeff``, ``add_force``, ``add_no_contact``, ``query_sdfs`` is
-on the device side).  Parameters are torch tensors and may require grad; geometry kernels run on the HIP device.
-Only the analytic (custom_mesh / custom_inertia) variants exist; marching-cubes meshes are SURVEY.md §8f N1.
+``faces``, ``dims``/``rad``, ``restitution``, ``fric_coeff``, ``add_force``, ``add_no_contact``, ``query_sdfs``).
+Parameters are torch tensors and may require grad; geometry kernels run on the HIP device.
+Meshes are the analytic ``custom_mesh`` ones; ``custom_inertia=False`` integrates the mesh on the device
+(dss_mesh_inertia).  Marching-cubes meshes are SURVEY.md §8f N1.
 """
 import math
 
 import numpy as np
 import torch
 
-from .. import meshes, world_abi as abi
+from .. import mass_properties, meshes, world_abi as abi
 from .utils import Defaults3D, get_tensor
 
 
@@ -60,6 +61,16 @@ class Body3D:
             return torch.zeros(6, dtype=torch.float64)
         return sum(f.force(t) for f in self.forces)
 
+    def query_sdfs(self, pts_loc, return_grads=True, return_overlapmask=False):
+        """`SDF3D.query_sdfs` (sdf_physics/physics3d/bodies.py:721-760) on the device: body-frame points ->
+        sdf (, normalised gradient) (, overlap mask).  Values only: the stepper differentiates contact geometry in
+        its own backward kernels, not through this query."""
+        return mass_properties.sdf_query(self.shape_type, self.shape_prm(), pts_loc, return_grads, return_overlapmask)
+
+    def _mesh_ang_inertia(self, mass):
+        """`SDF3D._get_ang_inertia` (bodies.py:713-714): volume integrals of the body's own mesh (values only)."""
+        return mass_properties.mesh_inertia(self.verts_np, self.faces_np, float(torch.as_tensor(mass).detach())).cpu()
+
 
 class SDFBox(Body3D):
     shape_type = abi.SHAPE_BOX
@@ -67,9 +78,9 @@ class SDFBox(Body3D):
     def __init__(self, pos, dims, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not (custom_mesh and custom_inertia):
-            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1); "
-                                      "use custom_mesh=True, custom_inertia=True")
+        if not custom_mesh:
+            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
+        self.custom_inertia = custom_inertia
         self.dims = get_tensor(dims)
         self.scale = torch.max(self.dims) * 1.5 / 2
         v, f, tie = meshes.box_mesh(self.dims.detach().cpu().numpy())
@@ -83,6 +94,8 @@ class SDFBox(Body3D):
         return self.dims
 
     def _get_ang_inertia(self, mass):   # bodies.py:796-797
+        if not self.custom_inertia:
+            return self._mesh_ang_inertia(mass)
         d = self.dims
         return mass * torch.diag(torch.stack([d[1] ** 2 + d[2] ** 2, d[0] ** 2 + d[2] ** 2, d[0] ** 2 + d[1] ** 2])) / 12
 
@@ -93,8 +106,9 @@ class SDFSphere(Body3D):
     def __init__(self, pos, rad, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not (custom_mesh and custom_inertia):
-            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1)")
+        if not custom_mesh:
+            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
+        self.custom_inertia = custom_inertia
         self.rad = get_tensor(rad)
         self.scale = self.rad * 1.5
         uv, uf = meshes.icosphere(4)
@@ -108,6 +122,8 @@ class SDFSphere(Body3D):
         return torch.cat([self.rad.reshape(1), self.rad.new_zeros(2)])
 
     def _get_ang_inertia(self, mass):   # bodies.py:993-994
+        if not self.custom_inertia:
+            return self._mesh_ang_inertia(mass)
         return 2.0 / 5.0 * mass * self.rad ** 2 * torch.eye(3, dtype=torch.float64)
 
 
@@ -118,8 +134,9 @@ class SDFCylinder(Body3D):
     def __init__(self, pos, rad, height, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not (custom_mesh and custom_inertia):
-            raise NotImplementedError("marching-cubes meshes / mesh inertia are not built yet (SURVEY.md §8f N1)")
+        if not custom_mesh:
+            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
+        self.custom_inertia = custom_inertia
         self.rad, self.height = get_tensor(rad), get_tensor(height)
         self.scale = torch.max(self.rad, self.height / 2) * 1.5
         self.verts_np, self.faces_np, self.vgrad_np = meshes.cylinder_mesh(float(self.rad.detach()), float(self.height.detach()))
@@ -132,5 +149,7 @@ class SDFCylinder(Body3D):
         return torch.stack([self.rad.reshape(()), self.height.reshape(()), self.rad.new_zeros(())])
 
     def _get_ang_inertia(self, mass):   # bodies.py:925-927
+        if not self.custom_inertia:
+            return self._mesh_ang_inertia(mass)
         a = (3 * self.rad ** 2 + self.height ** 2) / 12
         return mass * torch.diag(torch.stack([a, a, self.rad ** 2 / 2]))

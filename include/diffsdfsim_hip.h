@@ -252,6 +252,22 @@ size_t dss_igr_packed_doubles(void);
 int dss_igr_query(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
                   const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * World-construction side of the path
+ *
+ * dss_sdf_query replaces SDF3D.query_sdfs (sdf_physics/physics3d/bodies.py:721-760) for the analytic primitives:
+ *   pts [n][3] in the body frame (world units), prm = shape parameters in world units (box: dims; sphere: rad;
+ *   cylinder: rad, height) -> sdf [n], grad [n][3] (normalised; may be NULL = return_grads False),
+ *   overlap_mask [n] (1 inside the [-scale, scale]^3 query cube; may be NULL).  Outside the cube sdf = scale, grad = 0.
+ * dss_mesh_inertia replaces get_ang_inertia (bodies.py:260-395) for a pooled table of closed triangle meshes
+ *   (same table layout as DssWorld: verts [NV][3], faces [NF][3] mesh-local indices, mesh_voff/foff/nf [nmesh]):
+ *   J [nmesh][9] inertia about the mesh origin for mass[m] at uniform density, volume [nmesh] (may be NULL).
+ * ------------------------------------------------------------------------------------ */
+int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, double *sdf, double *grad,
+                  unsigned char *overlap_mask, void *stream);
+int dss_mesh_inertia(const double *verts, const int *faces, const int *mesh_voff, const int *mesh_foff, const int *mesh_nf,
+                     int nmesh, const double *mass, double *J, double *volume, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,3 +132,23 @@ def igr_query(pts, latent, Ws, bs):
     rc = L.dss_igr_query(_p(pts), _p(lat), _p(W0), _p(b0), _p(packed), _p(bh), _p(W8), _p(b8), n, _p(sdf), _p(grad), None)
     assert rc == 0
     return sdf, grad
+
+
+def sdf_query(shape_type, prm, pts):
+    L = lib()
+    pts = _c(pts); n = len(pts)
+    prm = _c(np.concatenate([np.asarray(prm, np.float64).reshape(-1), np.zeros(3)])[:3])
+    sdf = np.zeros(n); grad = np.zeros((n, 3)); mask = np.zeros(n, np.uint8)
+    rc = L.dss_sdf_query(int(shape_type), _p(prm), _p(pts), n, _p(sdf), _p(grad), _p(mask), None)
+    assert rc == 0
+    return sdf, grad, mask.astype(bool)
+
+
+def mesh_inertia(verts, faces, mass):
+    L = lib()
+    V = _c(verts); F = _c(faces, np.int32)
+    voff = np.zeros(1, np.int32); foff = np.zeros(1, np.int32); nf = np.array([len(F)], np.int32)
+    M = np.array([mass], np.float64); J = np.zeros(9); vol = np.zeros(1)
+    rc = L.dss_mesh_inertia(_p(V), _p(F), _p(voff), _p(foff), _p(nf), 1, _p(M), _p(J), _p(vol), None)
+    assert rc == 0
+    return J.reshape(3, 3), vol[0]
