@@ -3,15 +3,16 @@
 Same constructor arguments and attributes as the reference (``p``, ``pos``, ``rot``, ``v``, ``mass``, ``verts``,
 ``faces``, ``dims``/``rad``, ``restitution``, ``fric_coeff``, ``add_force``, ``add_no_contact``, ``query_sdfs``).
 Parameters are torch tensors and may require grad; geometry kernels run on the HIP device.
-Meshes are the analytic ``custom_mesh`` ones; ``custom_inertia=False`` integrates the mesh on the device
-(dss_mesh_inertia).  Marching-cubes meshes are SURVEY.md §8f N1.
+``custom_mesh=True`` gives the reference's analytic meshes; ``custom_mesh=False`` meshes the unit SDF with
+marching cubes on the device like ``SDF3D._create_mesh`` (bodies.py:706-711; the stepper does not yet carry
+shape-parameter gradients through those vertices).  ``custom_inertia=False`` integrates the mesh (dss_mesh_inertia).
 """
 import math
 
 import numpy as np
 import torch
 
-from .. import mass_properties, meshes, world_abi as abi
+from .. import mass_properties, meshes, meshsdf, world_abi as abi
 from .utils import Defaults3D, get_tensor
 
 
@@ -67,6 +68,13 @@ class Body3D:
         its own backward kernels, not through this query."""
         return mass_properties.sdf_query(self.shape_type, self.shape_prm(), pts_loc, return_grads, return_overlapmask)
 
+    def _marching_cubes_mesh(self):
+        """`SDF3D._create_mesh` (bodies.py:706-711): unit SDF on 128^3 -> marching cubes -> vertices * scale."""
+        scale = float(self.scale.detach())
+        v, f = meshsdf.primitive_mesh(self.shape_type, (self.shape_prm().detach() / scale), res=128)
+        v = (v.detach() * scale).cpu().numpy()
+        return v, f.cpu().numpy().astype(np.int64), np.zeros_like(v)
+
     def _mesh_ang_inertia(self, mass):
         """`SDF3D._get_ang_inertia` (bodies.py:713-714): volume integrals of the body's own mesh (values only)."""
         return mass_properties.mesh_inertia(self.verts_np, self.faces_np, float(torch.as_tensor(mass).detach())).cpu()
@@ -78,13 +86,14 @@ class SDFBox(Body3D):
     def __init__(self, pos, dims, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not custom_mesh:
-            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
         self.custom_inertia = custom_inertia
         self.dims = get_tensor(dims)
         self.scale = torch.max(self.dims) * 1.5 / 2
-        v, f, tie = meshes.box_mesh(self.dims.detach().cpu().numpy())
-        self.verts_np, self.faces_np, self.vgrad_np = v, f, 0.5 * tie
+        if custom_mesh:
+            v, f, tie = meshes.box_mesh(self.dims.detach().cpu().numpy())
+            self.verts_np, self.faces_np, self.vgrad_np = v, f, 0.5 * tie
+        else:
+            self.verts_np, self.faces_np, self.vgrad_np = self._marching_cubes_mesh()
         super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
 
     verts = property(lambda self: torch.as_tensor(self.verts_np))
@@ -106,13 +115,14 @@ class SDFSphere(Body3D):
     def __init__(self, pos, rad, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not custom_mesh:
-            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
         self.custom_inertia = custom_inertia
         self.rad = get_tensor(rad)
         self.scale = self.rad * 1.5
-        uv, uf = meshes.icosphere(4)
-        self.verts_np, self.faces_np, self.vgrad_np = uv * float(self.rad.detach()), uf, uv
+        if custom_mesh:
+            uv, uf = meshes.icosphere(4)
+            self.verts_np, self.faces_np, self.vgrad_np = uv * float(self.rad.detach()), uf, uv
+        else:
+            self.verts_np, self.faces_np, self.vgrad_np = self._marching_cubes_mesh()
         super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
 
     verts = property(lambda self: torch.as_tensor(self.verts_np))
@@ -134,12 +144,13 @@ class SDFCylinder(Body3D):
     def __init__(self, pos, rad, height, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH,
                  custom_inertia=Defaults3D.CUSTOM_INERTIA, **kw):
-        if not custom_mesh:
-            raise NotImplementedError("marching-cubes meshes are not built yet (SURVEY.md §8f N1); use custom_mesh=True")
         self.custom_inertia = custom_inertia
         self.rad, self.height = get_tensor(rad), get_tensor(height)
         self.scale = torch.max(self.rad, self.height / 2) * 1.5
-        self.verts_np, self.faces_np, self.vgrad_np = meshes.cylinder_mesh(float(self.rad.detach()), float(self.height.detach()))
+        if custom_mesh:
+            self.verts_np, self.faces_np, self.vgrad_np = meshes.cylinder_mesh(float(self.rad.detach()), float(self.height.detach()))
+        else:
+            self.verts_np, self.faces_np, self.vgrad_np = self._marching_cubes_mesh()
         super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
 
     verts = property(lambda self: torch.as_tensor(self.verts_np))

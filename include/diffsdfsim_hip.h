@@ -268,6 +268,22 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
 int dss_mesh_inertia(const double *verts, const int *faces, const int *mesh_voff, const int *mesh_foff, const int *mesh_nf,
                      int nmesh, const double *mass, double *J, double *volume, void *stream);
 
+/* Marching cubes + MeshSDF backward: replaces SDF3D._diff_marching_cubes (bodies.py:653-704).
+ *   phi [n0][n1][n2] SDF samples (x slowest, as torch.meshgrid(...).reshape(res,res,res)); inside <=> phi < iso.
+ *   ntri_tab [256], tri_tab [256][max_tri][3] (cube-edge ids): diffsdfsim_amd/mc_tables.py.
+ *   dss_mc_count  -> totals[0] = vertices, totals[1] = triangles (device ints; read them, allocate, then)
+ *   dss_mc_emit   -> verts [V][3] in grid-index units (the caller maps to [-1,1]: v/(res-1)*2-1), faces [F][3].
+ *   The workspace passed to dss_mc_emit must be the one dss_mc_count filled.
+ *   dss_meshsdf_backward: grad_prm[3] = sum_v -(grad_verts[v] . n_v) d phi / d unit_prm (v), analytic primitives,
+ *   unit frame of the reference (params already divided by the body scale, vertices in [-1,1]^3). */
+size_t dss_mc_workspace_bytes(int n0, int n1, int n2);
+int dss_mc_count(const double *phi, int n0, int n1, int n2, double iso, const int *ntri_tab, void *workspace,
+                 size_t workspace_bytes, int *totals, void *stream);
+int dss_mc_emit(const double *phi, int n0, int n1, int n2, double iso, const int *ntri_tab, const signed char *tri_tab,
+                int max_tri, const void *workspace, double *verts, int *faces, void *stream);
+int dss_meshsdf_backward(int shape_type, const double *unit_prm, const double *unit_verts, const double *grad_verts, int nv,
+                         double *grad_prm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,31 @@ def mesh_inertia(verts, faces, mass):
     rc = L.dss_mesh_inertia(_p(V), _p(F), _p(voff), _p(foff), _p(nf), 1, _p(M), _p(J), _p(vol), None)
     assert rc == 0
     return J.reshape(3, 3), vol[0]
+
+
+def marching_cubes(phi, iso=0.0):
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from diffsdfsim_amd import mc_tables
+    L = lib()
+    ntri, tri, _ = mc_tables.tables()
+    phi = _c(phi); n0, n1, n2 = phi.shape
+    L.dss_mc_workspace_bytes.restype = ctypes.c_size_t
+    nb = L.dss_mc_workspace_bytes(n0, n1, n2)
+    ws = np.zeros(nb, np.uint8); tot = np.zeros(2, np.int32)
+    ntri_c = _c(ntri, np.int32); tri_c = _c(tri, np.int8)
+    rc = L.dss_mc_count(_p(phi), n0, n1, n2, ctypes.c_double(iso), _p(ntri_c), _p(ws), ctypes.c_size_t(nb), _p(tot), None)
+    assert rc == 0
+    V = np.zeros((max(int(tot[0]), 1), 3)); F = np.zeros((max(int(tot[1]), 1), 3), np.int32)
+    rc = L.dss_mc_emit(_p(phi), n0, n1, n2, ctypes.c_double(iso), _p(ntri_c), _p(tri_c), mc_tables.MAX_TRI, _p(ws), _p(V), _p(F), None)
+    assert rc == 0
+    return V[: tot[0]], F[: tot[1]]
+
+
+def meshsdf_backward(shape_type, unit_prm, unit_verts, gbar):
+    L = lib()
+    prm = _c(np.concatenate([np.asarray(unit_prm, np.float64).reshape(-1), np.zeros(3)])[:3])
+    V = _c(unit_verts); Gb = _c(gbar); out = np.zeros(3)
+    rc = L.dss_meshsdf_backward(int(shape_type), _p(prm), _p(V), _p(Gb), len(V), _p(out), None)
+    assert rc == 0
+    return out

@@ -179,6 +179,7 @@ inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline unsigned __float_as_uint(float f) { unsigned r; std::memcpy(&r, &f, 4); return r; }
 inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
