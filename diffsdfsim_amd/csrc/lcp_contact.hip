@@ -802,7 +802,9 @@ lcp_contact_forward_kernel(const double *Mblk_, const double *pvec_, const doubl
 // operands is re-read from memory inside the iteration, d is divided out once per iteration instead of once per
 // pass, and sum(s z) after the affine step needs no pass at all.  Arithmetic per contact is expression for
 // expression that of lcp_contact_forward_kernel (the streaming form, kept for maxc > 128): results are bit-identical.
-template <int ND>
+// N = compiled size of the register-resident factorisation (54, 18) or 0 = LDS fallback for other n <= 64.  With
+// N > 0 the factored rows stay in registers from the affine solve to the corrector solve of the same iteration.
+template <int ND, int N>
 __global__ void __launch_bounds__(64)
 lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const double *A_, const double *bvec_,
                                const double *cop_, const int *cbody_, const int *ncs, const int *active, int nb, int neq,
@@ -822,7 +824,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
     const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
     double *x_out = x_out_ + (size_t)sc * nz, *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
     double *nu = neq ? nu_ + (size_t)sc * neq : nullptr;
-    L.kf = ws_ + (size_t)sc * (5 * NR * maxc + 64 * 64) + (size_t)5 * NR * maxc;
+    L.kf = N > 0 ? nullptr : ws_ + (size_t)sc * (5 * NR * maxc + 64 * 64) + (size_t)5 * NR * maxc;
     L.Ag = A;
     int nc = ncs[sc];
     if (nc > maxc) nc = maxc;
@@ -995,11 +997,26 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
                 for (int j = 0; j < 9; ++j) L.cw[9 * (l0 + WAVE * r) + j] = Cv[r][j];
         __syncthreads();
         assemble_K(L, Mblk, A, cbody, nc);
+        RegK<(N > 0 ? N : 1)> R;
         {
-            double rhs = 0.0;
+            double rhs = 0.0, sol;
             if (lane < nz) rhs = -rx - L.g2[lane];
             else if (lane < n) rhs = -ry;
-            const double sol = kkt_factor_solve(L, rhs);
+            if constexpr (N > 0) {
+                // row `lane` of K = [[H, A^T],[A, 0]]: H from LDS, equality rows straight from global
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double v = 0.0;
+                    if (lane < nz) v = (j < nz) ? L.K[lane * L.lda + j] : A[(j - nz) * nz + lane];
+                    else if (lane < N) v = (j < nz) ? A[(lane - nz) * nz + j] : 0.0;
+                    R.a[j] = v;
+                }
+                regk_factor_natural<N>(R);
+                sol = regk_solve_natural<N>(R, rhs);
+                __syncthreads();
+            } else {
+                sol = kkt_factor_solve(L, rhs);
+            }
             if (lane < n) L.dxa[lane] = sol;
         }
         __syncthreads();
@@ -1058,8 +1075,9 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
         __syncthreads();
         gather<1>(L, L.g1, nullptr);
         {
-            double rhs = (lane < nz) ? L.g1[lane] : 0.0;
-            const double sol = kkt_solve(L, rhs);
+            double rhs = (lane < nz) ? L.g1[lane] : 0.0, sol;
+            if constexpr (N > 0) sol = regk_solve_natural<N>(R, rhs);
+            else sol = kkt_solve(L, rhs);
             if (lane < n) L.sol[lane] = sol;
         }
         __syncthreads();
@@ -1249,14 +1267,14 @@ int dss_lcp_contact_forward(const double *Mblk, const double *pvec, const double
     const size_t lds = lds_bytes(nb, neq, maxc);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     if (maxc <= 128) {   // two contacts per lane: IPM state in registers
-        if (fric_dirs == 8)
-            hipLaunchKernelGGL(lcp_contact_forward_reg_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A,
-                               bvec, cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu,
-                               iters, status, (double *)workspace);
-        else
-            hipLaunchKernelGGL(lcp_contact_forward_reg_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A,
-                               bvec, cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu,
-                               iters, status, (double *)workspace);
+        const int n = 6 * nb + neq;
+#define DSS_LAUNCH_REG(ND_, N_)                                                                                         \
+        hipLaunchKernelGGL((lcp_contact_forward_reg_kernel<ND_, N_>), dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, \
+                           A, bvec, cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, \
+                           iters, status, (double *)workspace)
+        if (fric_dirs == 8) { if (n == 54) DSS_LAUNCH_REG(4, 54); else if (n == 18) DSS_LAUNCH_REG(4, 18); else DSS_LAUNCH_REG(4, 0); }
+        else { if (n == 54) DSS_LAUNCH_REG(2, 54); else if (n == 18) DSS_LAUNCH_REG(2, 18); else DSS_LAUNCH_REG(2, 0); }
+#undef DSS_LAUNCH_REG
     } else if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_forward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, pvec, A, bvec,
                            cop, cbody, nc, active, nb, neq, maxc, eps, not_improved_lim, max_iter, x, lam, slack, nu, iters,
