@@ -922,6 +922,8 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
 
     double best = 0.0;
     int have_best = 0, not_improved = 0, it = 0;
+    LSTAMP_INIT;
+    LSTAMP(0);
     for (it = 0; it < max_iter; ++it) {
         // ---- residuals (batch.py:117-131), the affine right-hand side and K(d) ------------------
         double acc_rz = 0.0, acc_sz = 0.0, Cv[CPL][9];
@@ -958,7 +960,9 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
         acc_rz = wave_sum(acc_rz);
         const double sz = wave_sum(acc_sz);
         __syncthreads();
+        LSTAMP(1);
         gather<2>(L, L.g1, L.g2);  // g1 = G^T z, g2 = G^T W (rz - s)
+        LSTAMP(2);
         double rx = 0.0, ry = 0.0;
         if (lane < nz) {
             rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane];
@@ -987,6 +991,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             ++not_improved;
         }
         if (not_improved == not_improved_lim || best < eps || mu > 1e32) break;
+        LSTAMP(3);
 
         // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
         __syncthreads();
@@ -996,7 +1001,9 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
 #pragma unroll
                 for (int j = 0; j < 9; ++j) L.cw[9 * (l0 + WAVE * r) + j] = Cv[r][j];
         __syncthreads();
+        LSTAMP(4);
         assemble_K(L, Mblk, A, cbody, nc);
+        LSTAMP(5);
         RegK<(N > 0 ? N : 1)> R;
         {
             double rhs = 0.0, sol;
@@ -1020,6 +1027,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             if (lane < n) L.dxa[lane] = sol;
         }
         __syncthreads();
+        LSTAMP(7);
         StepAcc stz, sts;
         const int l1 = opaque_lane(lane);
 #pragma unroll
@@ -1043,6 +1051,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             }
         }
         double alpha = fmin(fmin(stz.finish(), sts.finish()), 1.0);
+        LSTAMP(8);
         double t3 = 0.0;
 #pragma unroll
         for (int r = 0; r < CPL; ++r)
@@ -1073,6 +1082,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             for (int j = 0; j < 3; ++j) L.cw[3 * c + j] = w[j];
         }
         __syncthreads();
+        LSTAMP(9);
         gather<1>(L, L.g1, nullptr);
         {
             double rhs = (lane < nz) ? L.g1[lane] : 0.0, sol;
@@ -1081,6 +1091,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             if (lane < n) L.sol[lane] = sol;
         }
         __syncthreads();
+        LSTAMP(10);
         StepAcc stz2, sts2;
         const int l3 = opaque_lane(lane);
 #pragma unroll
@@ -1106,6 +1117,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
         }
         alpha = fmin(0.999 * fmin(stz2.finish(), sts2.finish()), 1.0);
         __syncthreads();
+        LSTAMP(11);
         if (lane < n) L.xv[lane] += alpha * (L.dxa[lane] + L.sol[lane]);
 #pragma unroll
         for (int r = 0; r < CPL; ++r)
@@ -1115,6 +1127,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
                 z[r][q] += alpha * dzv[r][q];
             }
         __syncthreads();
+        LSTAMP(12);
     }
     if (lane == 0) { iters[sc] = it; status[sc] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
 }

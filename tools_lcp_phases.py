@@ -14,7 +14,7 @@ st = torch.zeros(B * 16, dtype=torch.int64, device="cuda")
 E.be.lib.dss_diag_set_lcp_stamps(ctypes.c_void_p(st.data_ptr()), E.be.stream())
 E.step(); torch.cuda.synchronize()
 d = st.cpu().numpy().reshape(B, 16) / 100.0
-names = ["pre", "P1 resid pass", "gather2", "resid/best", "Cmat pass", "assemble_K", "factor_K", "solve aff", "P4 pass", "sigma+P5 pass", "gather1+solve cor", "P6 pass", "update"]
+names = ["pre", "P1 resid+Cmat pass", "gather2", "resid/best", "C to LDS", "assemble_K", "-", "factor+solve aff", "P4 pass", "sigma+P5 pass", "gather1+solve cor", "P6 pass", "update"]
 tot = d.sum(1).mean()
 print("iters", E.get("lcp_iters").mean(), "nc mean", E.get("nc").mean(), "total us/scene", round(tot, 1))
 for i, n in enumerate(names):

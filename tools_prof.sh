@@ -9,4 +9,4 @@ f = glob.glob("gpurun_out/prof_last/*/*kernel_stats.csv")[0]
 for r in list(csv.DictReader(open(f)))[:12]:
     print("%-62s %4s calls  avg %9.1f us  %5s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
-tail -1 gpurun_out/prof_last.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'])"
+grep "^{" gpurun_out/prof_last.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(\"ms_per_step\", d[\"ms_per_step\"])"
