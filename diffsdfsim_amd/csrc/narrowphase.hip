@@ -192,6 +192,7 @@ template <class G> struct ScratchT {
     double hp[3 * G::HCAP];   // cluster points for the hull
     int hidx[G::HCAP];
     unsigned char hflag[G::HCAP];
+    unsigned char cst[G::HCAP];   // filter state of a contact: 0 unassigned, 1 clustered, 2 kept, 255 no normal
 };
 
 // ordered compaction: returns this thread's output slot (or -1) and updates the running count
@@ -814,14 +815,22 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (tid == 0) cstate[0] = -2;  // kept
         nkeep = ncon;
     } else {
+        // The state of every contact lives in LDS bytes while the clusters are formed (a wavefront-sized group needs
+        // ncon <= HCAP anyway; a workgroup falls back to the global array beyond its LDS capacity), and the six
+        // numbers a contact contributes (normal, p1) are fetched in one batch per round: every dependent global
+        // round trip costs a microsecond here.
+        const bool lds_state = ncon <= G::HCAP;
+        if (!lds_state && G::BT == 64) return 1;
+        auto get_state = [&](int k) -> int { return lds_state ? (int)S.cst[k] : cstate[k]; };
+        auto set_state = [&](int k, int v) { if (lds_state) S.cst[k] = (unsigned char)v; else cstate[k] = v; };
         for (int k = tid; k < ncon; k += G::BT) {
             const double nn = sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
-            cstate[k] = nn > 1e-12 ? 0 : -1;
+            set_state(k, nn > 1e-12 ? 0 : 255);
         }
         G::sync();
         for (int cl = 1; cl <= ncon; ++cl) {
             int mine = -1;
-            for (int k = tid; k < ncon; k += G::BT) if (cstate[k] == 0) { mine = k; break; }
+            for (int k = tid; k < ncon; k += G::BT) if (get_state(k) == 0) { mine = k; break; }
             const int seed = block_argmin(mine >= 0 ? (double)mine : INFINITY, mine, S);
             if (seed < 0) break;
             const double sn[3] = {CB(18, seed), CB(19, seed), CB(20, seed)};
@@ -830,23 +839,30 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             for (int base = 0; base < ncon; base += G::BT) {
                 const int k = base + tid;
                 int in = 0;
-                if (k < ncon && cstate[k] == 0) {
-                    const double d = fmin(CB(18, k) * sn[0] + CB(19, k) * sn[1] + CB(20, k) * sn[2], 1.0);
+                double p1v[3] = {0.0, 0.0, 0.0};
+                if (k < ncon && get_state(k) == 0) {
+                    const double nk[3] = {CB(18, k), CB(19, k), CB(20, k)};
+                    for (int i = 0; i < 3; ++i) p1v[i] = CB(21 + i, k);
+                    const double d = fmin(nk[0] * sn[0] + nk[1] * sn[1] + nk[2] * sn[2], 1.0);
                     in = acos(d) < 1e-2;
                 }
                 const int slot = compact_slot(in, m, S);
                 if (slot >= 0) {
-                    cstate[k] = cl;
-                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = CB(21 + i, k); }
+                    set_state(k, 1);
+                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = p1v[i]; }
                 }
             }
             G::sync();
             if (m > G::HCAP) { if (G::BT == 64) return 1; over |= 2; m = G::HCAP; }
             cluster_hull(S, m, W.eps);
-            for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) cstate[S.hidx[j]] = -2;
+            for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) set_state(S.hidx[j], 2);
             G::sync();
         }
-        for (int k = tid; k < ncon; k += G::BT) nkeep += (cstate[k] == -2);
+        for (int k = tid; k < ncon; k += G::BT) {
+            const int kept = get_state(k) == 2;
+            cstate[k] = kept ? -2 : 0;     // the final stage reads the global array
+            nkeep += kept;
+        }
         nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
     }
 

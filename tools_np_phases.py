@@ -5,7 +5,7 @@ from diffsdfsim_amd import scenes
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 spec = scenes.box_stack(B, nbox=7, seed=1)
-E = BatchEngine(spec, maxc=192, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
+E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
 np_ = E.nb * (E.nb - 1)
 dbg = torch.zeros(B * np_ * 8, dtype=torch.int64, device="cuda")
 E.W.dbg_stamps = dbg.data_ptr()
