@@ -101,68 +101,87 @@ __device__ inline bool box_hits(const Region &r, const double *bx)
 }
 
 // ---- _overlap ---------------------------------------------------------------------------------
+// "Does any vertex of one body lie in the other's query cube", both ways, for every undirected pair.  One workgroup
+// per scene, its four wavefronts take the pairs round robin (no barrier inside a pair: the work per pair is a short
+// chain of dependent loads).  The surviving pairs of the scene are appended to the work lists with ONE atomic per
+// list and scene: a per-pair atomicAdd on two global counters serialises tens of thousands of wavefronts.
+constexpr int OV_RUN = 256;   // vertices per culling box (engine.mesh_table CHUNK)
 __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
 {
-    const int nup = W.nb * (W.nb - 1) / 2, np = npairs_of(W.nb);
-    const int sc = blockIdx.x / nup, up = blockIdx.x % nup, tid = threadIdx.x;
+    __shared__ unsigned char s_ok[64 * 63 / 2];
+    const int nb = W.nb, nup = nb * (nb - 1) / 2, np = npairs_of(nb);
+    const int sc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!W.active[sc]) return;
-    int i = 0, rem = up;
-    while (rem >= W.nb - 1 - i) { rem -= W.nb - 1 - i; ++i; }
-    const int j = i + 1 + rem;
-    int *flag = W.ovl + ((size_t)sc * W.nb + i) * W.nb + j;
-    const int dp_ij = i * (W.nb - 1) + (j - 1), dp_ji = j * (W.nb - 1) + i;
-    __shared__ unsigned long long s_mask[NT / 64];
-    int ok = !W.no_contact[i * W.nb + j];
-    if (ok) {
-        BodyD A, Bd;
-        load_body(W, sc, i, A);
-        load_body(W, sc, j, Bd);
-        for (int dir = 0; dir < 2 && ok; ++dir) {
-            const BodyD &src = dir ? Bd : A, &dst = dir ? A : Bd;
-            const double s = dst.g.shape.scale;
-            Region reg;
-            region_of(src.g, dst.g, 1e-9, reg);
-            const double *vbox = W.vch_box + (size_t)W.mesh_vch_off[src.mesh] * 6;
-            const int nch = (src.nv + NT - 1) / NT;
-            int found = 0;
-            // culling boxes tested in parallel, 256 runs at a time; only runs that can reach dst's cube are walked
-            for (int cb0 = 0; cb0 < nch && !found; cb0 += NT) {
-                const int ch = cb0 + tid;
-                const unsigned long long hitm = __ballot(ch < nch && box_hits(reg, vbox + (size_t)ch * 6));
-                if ((tid & 63) == 0) s_mask[tid >> 6] = hitm;
-                __syncthreads();
-                for (int w = 0; w < NT / 64 && !found; ++w) {
-                    unsigned long long m = s_mask[w];
+    for (int up = wv; up < nup; up += NT / 64) {
+        int i = 0, rem = up;
+        while (rem >= nb - 1 - i) { rem -= nb - 1 - i; ++i; }
+        const int j = i + 1 + rem;
+        int ok = !W.no_contact[i * nb + j];
+        if (ok) {
+            BodyD A, Bd;
+            load_body(W, sc, i, A);
+            load_body(W, sc, j, Bd);
+            for (int dir = 0; dir < 2 && ok; ++dir) {
+                const BodyD &src = dir ? Bd : A, &dst = dir ? A : Bd;
+                const double s = dst.g.shape.scale;
+                Region reg;
+                region_of(src.g, dst.g, 1e-9, reg);
+                const double *vbox = W.vch_box + (size_t)W.mesh_vch_off[src.mesh] * 6;
+                const int nch = (src.nv + OV_RUN - 1) / OV_RUN;
+                int found = 0;
+                // culling boxes tested 64 at a time; only runs that can reach dst's cube are walked
+                for (int cb0 = 0; cb0 < nch && !found; cb0 += 64) {
+                    const int ch = cb0 + lane;
+                    unsigned long long m = __ballot(ch < nch && box_hits(reg, vbox + (size_t)ch * 6));
                     while (m && !found) {
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        const int v = (cb0 + 64 * w + b) * NT + tid;
                         int hit = 0;
-                        if (v < src.nv) {
-                            double p[3];
-                            to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
-                            hit = (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+#pragma unroll
+                        for (int sub = 0; sub < OV_RUN / 64; ++sub) {
+                            const int v = (cb0 + b) * OV_RUN + sub * 64 + lane;
+                            if (v < src.nv) {
+                                double p[3];
+                                to_frame(src.g, dst.g, W.verts + (size_t)(src.voff + v) * 3, p);
+                                hit |= (-s <= p[0] && p[0] <= s && -s <= p[1] && p[1] <= s && -s <= p[2] && p[2] <= s);
+                            }
                         }
-                        found = __syncthreads_or(hit);
+                        found = __ballot(hit) != 0ull;
                     }
                 }
-                __syncthreads();
+                ok = found;
             }
-            ok = found;
+        }
+        if (lane == 0) {
+            s_ok[up] = (unsigned char)ok;
+            W.ovl[((size_t)sc * nb + i) * nb + j] = ok;
+            if (!ok) {
+                W.pc_count[(size_t)sc * np + i * (nb - 1) + (j - 1)] = 0;
+                W.pc_count[(size_t)sc * np + j * (nb - 1) + i] = 0;
+            }
         }
     }
+    __syncthreads();
+    // list 0: items a whole workgroup works on (big mesh searched), list 1: one wavefront each
     if (tid == 0) {
-        *flag = ok;
-        if (ok) {
-            // list 0: items a whole workgroup works on (big mesh searched), list 1: one wavefront each
-            const int cap = W.B * np;
-            const int li = W.mesh_nf[W.mesh_id[(size_t)sc * W.nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
-            const int lj = W.mesh_nf[W.mesh_id[(size_t)sc * W.nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
-            W.pair_list[(size_t)li * cap + atomicAdd(W.n_pairs + 2 * li, 1)] = sc * np + dp_ij;
-            W.pair_list[(size_t)lj * cap + atomicAdd(W.n_pairs + 2 * lj, 1)] = sc * np + dp_ji;
-        } else {
-            W.pc_count[(size_t)sc * np + dp_ij] = 0;
-            W.pc_count[(size_t)sc * np + dp_ji] = 0;
+        int cnt[2] = {0, 0};
+        for (int up = 0, i = 0, j = 1; up < nup; ++up) {
+            if (s_ok[up]) {
+                ++cnt[W.mesh_nf[W.mesh_id[(size_t)sc * nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1];
+                ++cnt[W.mesh_nf[W.mesh_id[(size_t)sc * nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1];
+            }
+            if (++j == nb) { ++i; j = i + 1; }
+        }
+        const int cap = W.B * np;
+        int at[2] = {cnt[0] ? atomicAdd(W.n_pairs, cnt[0]) : 0, cnt[1] ? atomicAdd(W.n_pairs + 2, cnt[1]) : 0};
+        for (int up = 0, i = 0, j = 1; up < nup; ++up) {
+            if (s_ok[up]) {
+                const int li = W.mesh_nf[W.mesh_id[(size_t)sc * nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
+                const int lj = W.mesh_nf[W.mesh_id[(size_t)sc * nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
+                W.pair_list[(size_t)li * cap + at[li]++] = sc * np + i * (nb - 1) + (j - 1);
+                W.pair_list[(size_t)lj * cap + at[lj]++] = sc * np + j * (nb - 1) + i;
+            }
+            if (++j == nb) { ++i; j = i + 1; }
         }
     }
 }
@@ -1021,7 +1040,7 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
     if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
     (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // {count, cursor} x {block, wave, deferred}
-    hipLaunchKernelGGL(overlap_kernel, dim3(W.B * nup), dim3(NT), 0, stream, W);
+    hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(NT), 0, stream, W);
     // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
     const int grid = np_grid(W.B, W.nb);
     hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);
