@@ -111,6 +111,35 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     }
 }
 
+// Ordered per-body sums of per-contact pieces:
+//   sums[b * NC + q] = sum over contacts c, in contact order, of [body1(c) = b] cs[row0[q]][c] + [body2(c) = b] cs[row1[q]][c].
+// One lane per (body, component) instead of one lane per body walking every component: the loads of a contact do not
+// depend on the running sums, so the unrolled loop keeps four contacts in flight; a term that does not belong to the
+// lane's body is added as 0.0, which leaves the sum -- and therefore its summation order -- exactly as before.
+template <int NC>
+__device__ inline void contact_sums(const int *body, int MX, int nc, int nb, const double *cs, const int *row0,
+                                    const int *row1, double *sums)
+{
+    const int lane = threadIdx.x;
+    for (int e = lane; e < nb * NC; e += 64) {
+        const int b = e / NC, q = e % NC;
+        const double *c0 = cs + (size_t)row0[q] * MX, *c1 = cs + (size_t)row1[q] * MX;
+        double acc = 0.0;
+        int c = 0;
+        for (; c + 4 <= nc; c += 4) {
+            int b1[4], b2[4];
+            double v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { b1[u] = body[c + u]; b2[u] = body[MX + c + u]; v0[u] = c0[c + u]; v1[u] = c1[c + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc += (b1[u] == b) ? v0[u] : 0.0; acc += (b2[u] == b) ? v1[u] : 0.0; }
+        }
+        for (; c < nc; ++c) { acc += (body[c] == b) ? c0[c] : 0.0; acc += (body[MX + c] == b) ? c1[c] : 0.0; }
+        sums[e] = acc;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
 {
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
@@ -236,19 +265,15 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
     }
     __syncthreads();
+    __shared__ double s_sums[64 * 10];
+    {
+        static constexpr int row0[10] = {0, 1, 2, 3, 4, 5, 6, 14, 15, 16}, row1[10] = {7, 8, 9, 10, 11, 12, 13, 17, 18, 19};
+        contact_sums<10>(v.body_n, MX, v.nc_n, nb, cs, row0, row1, s_sums);
+    }
     if (lane < nb) {
-        double ap[7], gp[3] = {0, 0, 0};
-        for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i];
-        for (int c = 0; c < v.nc_n; ++c) {
-            if (v.body_n[c] == lane) {
-                for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)i * MX + c];
-                for (int i = 0; i < 3; ++i) gp[i] += cs[(size_t)(14 + i) * MX + c];
-            }
-            if (v.body_n[MX + c] == lane) {
-                for (int i = 0; i < 7; ++i) ap[i] += cs[(size_t)(7 + i) * MX + c];
-                for (int i = 0; i < 3; ++i) gp[i] += cs[(size_t)(17 + i) * MX + c];
-            }
-        }
+        double ap[7], gp[3];
+        for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i] + s_sums[10 * lane + i];
+        for (int i = 0; i < 3; ++i) gp[i] = s_sums[10 * lane + 7 + i];
         for (int i = 0; i < 3; ++i) A.g_prm[((size_t)sc * nb + lane) * 3 + i] += gp[i];
         if (ev) {   // pieces of H.backward that land on this body: moved pose, new velocity, f/m
             double vx[6] = {0, 0, 0, 0, 0, 0}, ab[3] = {0, 0, 0};
@@ -422,6 +447,11 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
         cs[(size_t)13 * MX + c] = 0.5 * rcbar;
     }
     __syncthreads();
+    __shared__ double s_sums[64 * 8];
+    {
+        static constexpr int row0[8] = {0, 1, 2, 3, 4, 5, 12, 13}, row1[8] = {6, 7, 8, 9, 10, 11, 12, 13};
+        contact_sums<8>(v.body_k, MX, v.nc_k, nb, cs, row0, row1, s_sums);
+    }
     if (lane < nb) {
         const size_t bi = (size_t)sc * nb + lane;
         const double *vk = v.vel_k + 6 * lane, *ub = du + 6 * lane;
@@ -437,11 +467,8 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) Iwbar[3 * r + c] = ub[r] * vk[c] + dM[36 * lane + 6 * r + c];
         for (int i = 0; i < 6; ++i) A.g_fext[bi * 6 + i] += v.dt * ub[i];
-        double fricb = 0.0, restb = 0.0;
-        for (int c = 0; c < v.nc_k; ++c) {
-            if (v.body_k[c] == lane) { for (int i = 0; i < 6; ++i) av[i] += cs[(size_t)i * MX + c]; fricb += cs[(size_t)12 * MX + c]; restb += cs[(size_t)13 * MX + c]; }
-            if (v.body_k[MX + c] == lane) { for (int i = 0; i < 6; ++i) av[i] += cs[(size_t)(6 + i) * MX + c]; fricb += cs[(size_t)12 * MX + c]; restb += cs[(size_t)13 * MX + c]; }
-        }
+        for (int i = 0; i < 6; ++i) av[i] += s_sums[8 * lane + i];
+        const double fricb = s_sums[8 * lane + 6], restb = s_sums[8 * lane + 7];
         for (int i = 0; i < 6; ++i) a_vel[6 * lane + i] = av[i];
         A.g_mass[bi] += mbar;
         A.g_fric[bi] += fricb;
