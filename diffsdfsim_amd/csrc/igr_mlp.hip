@@ -21,6 +21,7 @@
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"
+#include "mfma_f64.h"
 #include "wave_utils.h"
 
 namespace {
@@ -28,28 +29,8 @@ using namespace dss;
 
 constexpr int H = 128, NL = 9, DIN = 5, LDX = H + 1;
 
-#if defined(DSS_EMU)
-typedef struct { double x, y, z, w; } acc4;
-#else
-typedef double acc4 __attribute__((ext_vector_type(4)));
-#endif
-
-__device__ inline acc4 mfma(double a, double b, acc4 c)
-{
-#if defined(DSS_EMU)
-    return dss_emu_mfma_f64_16x16x4(a, b, c);
-#else
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-#endif
-}
-__device__ inline double &comp(acc4 &v, int i)
-{
-#if defined(DSS_EMU)
-    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
-#else
-    return reinterpret_cast<double *>(&v)[i];
-#endif
-}
+__device__ inline acc4 mfma(double a, double b, acc4 c) { return mfma_f64_16x16x4(a, b, c); }
+__device__ inline double &comp(acc4 &v, int i) { return acc_comp(v, i); }
 
 // softplus(z, beta=100, threshold=20) and its derivative, torch.nn.Softplus semantics
 __device__ inline void softplus100(double z, double &h, double &dh)
