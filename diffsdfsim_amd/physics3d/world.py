@@ -1,8 +1,8 @@
 """World3D / BatchWorld3D / run_world -- the reference's world surface on top of the HIP engine.
 
 Mirrors sdf_physics/physics3d/world.py:32-205 and lcp_physics/physics/world.py:38-139 for what demos/ and
-experiments/ touch: constructor keywords, ``step(fixed_dt)``, ``t``, ``dt``, ``bodies``, ``contacts``,
-``trajectory``, ``run_world``.  One outer step is ONE torch.autograd node (``_StepFn``): its forward runs the
+experiments/ touch: constructor keywords, ``step(fixed_dt)``, ``undo_step()``, ``t``, ``dt``, ``v``, ``set_v``,
+``set_p``, ``bodies``, ``contacts``, ``trajectory``, ``observations``, ``run_world``.  One outer step is ONE torch.autograd node (``_StepFn``): its forward runs the
 attempt loop of the device engine, its backward runs the reverse tape sweep of csrc/step_bwd.hip, so
 ``loss.backward()`` reaches body parameters (dims, rad, mass, fric_coeff, restitution, forces) and the initial
 state exactly as it does through the reference's Python graph.  The adjoint of the contact geometry, which
@@ -142,6 +142,8 @@ class World3D(BatchWorld3D):
         self.vel = st(lambda b: b.v).to(self.device)
         self.eps, self.tol, self.fric_dirs = eps, tol, fric_dirs
         self._t = 0.0
+        self.observations = []      # filled by experiment code, as in the reference (world.py:66)
+        self._start = None
         self._sync_bodies()
 
     t = property(lambda self: self._t)
@@ -162,8 +164,12 @@ class World3D(BatchWorld3D):
             out.append(((tt(g[0:3, c]), tt(g[3:6, c]), tt(g[6:9, c]), tt(g[9, c])), int(b[0, c]), int(b[1, c])))
         return out
 
+    _UNDO_ARRAYS = ("t", "nc", "c_body", "c_face", "c_abc", "c_geom", "last_dt", "toc", "nsub")
+
     def step(self, fixed_dt=False):
         self.params = self._ptensors(self._t)      # forces may depend on time (ExternalForce3D.force_func)
+        E = self.engine
+        self._start = (self._t, self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}, self._n_nodes)
         had = bool(BatchWorld3D.step(self, fixed_dt)[0])
         self._t = float(self.engine.get("t")[0])
         self._sync_bodies()
@@ -172,6 +178,34 @@ class World3D(BatchWorld3D):
 
     def get_v(self):
         return self.vel[0].reshape(-1)
+
+    v = property(get_v)
+
+    def set_v(self, new_v):
+        """lcp_physics/physics/world.py:384-387: flat [6 nb] generalized velocities."""
+        self.vel = new_v.reshape(1, len(self.bodies), 6).to(self.device)
+        self._sync_bodies()
+
+    def set_p(self, new_p):
+        """sdf_physics/physics3d/world.py:52-54: flat [7 nb] poses (quaternion wxyz + position per body).  As in the
+        reference the contact list is not refreshed: it belongs to the pose at the end of the last step."""
+        self.pose = new_p.reshape(1, len(self.bodies), 7).to(self.device)
+        self._sync_bodies()
+
+    def undo_step(self):
+        """lcp_physics/physics/world.py:106-116: back to the state (time, poses, velocities, contacts) at the start
+        of the last step; its trajectory entries are dropped."""
+        if getattr(self, "_start", None) is None:
+            return
+        t0, pose0, vel0, arrs, nodes = self._start
+        E = self.engine
+        for k, a in arrs.items():
+            E.arr[k].copy_(a)
+        self._t, self.pose, self.vel, self._n_nodes = t0, pose0, vel0, nodes
+        self._sync_bodies()
+        while self.trajectory and self.trajectory[-1][0] > self._t:
+            self.trajectory.pop()
+        self._start = None
 
 
 def run_world(world, fixed_dt=False, animation_dt=None, run_time=10, print_time=True, scene=None, recorder=None, **_render):

@@ -76,3 +76,28 @@ def test_engine_plugin_solve_dynamics_matches_the_step():
     w.step(fixed_dt=True)
     if int(w.engine.get("nsub")[0]) == n0 + 1:      # accepted at the first attempt: same dt, same solve
         assert torch.allclose(v_new.reshape(2, 6), w.vel[0], rtol=0, atol=1e-14)
+
+
+def test_undo_step_set_p_set_v():
+    """World surface used by the experiments (lcp_physics/physics/world.py:106-116, 381-391): undo_step returns to
+    the start of the last step (time, poses, velocities, contacts, trajectory), after which the same step repeats
+    bit for bit; set_v / set_p replace the state of all bodies."""
+    g = R.load_rollout("rollout_sphere_notoc")
+    w, floor, ball, rad = build_sphere_world(g, toc=True)
+    for _ in range(10):
+        w.step(fixed_dt=True)
+    t0, p0, v0, nc0, ntraj = w.t, w.pose.clone(), w.v.clone(), len(w.contacts), len(w.trajectory)
+    w.step(fixed_dt=True)
+    p1, v1, t1 = w.pose.clone(), w.v.clone(), w.t
+    w.undo_step()
+    assert w.t == t0 and torch.equal(w.pose, p0) and torch.equal(w.v, v0)
+    assert len(w.contacts) == nc0 and len(w.trajectory) == ntraj and torch.equal(ball.p, p0[0, 1])
+    w.step(fixed_dt=True)
+    assert w.t == t1 and torch.equal(w.pose, p1) and torch.equal(w.v, v1)
+    nv = w.v.clone(); nv[9] = 0.25                      # give the ball a push along x
+    w.set_v(nv)
+    npose = w.pose.reshape(-1).clone(); npose[7 + 5] += 0.1
+    w.set_p(npose)
+    assert float(ball.v[3]) == 0.25 and abs(float(ball.pos[1]) - float(p1[0, 1, 5]) - 0.1) < 1e-15
+    w.step(fixed_dt=True)
+    assert torch.isfinite(w.pose).all() and w.observations == []
