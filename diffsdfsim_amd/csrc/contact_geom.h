@@ -30,24 +30,30 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
     return acc;
 }
 
-// One contact from a barycentric point on a triangle of body 1's mesh.
-//   tri: the three vertices (body-1 frame), abc: barycentrics (constants)
-//   out: n (world), p1, p2 (world-frame offsets from the body origins), pen = -phi_2
+// One contact from a barycentric point on a triangle of body 1's mesh, in two halves (the backward differentiates
+// the second half alone for the inputs that only enter there).
+//   head: body-1 side.  tri: the three vertices (body-1 frame), abc: barycentrics (constants)
+//         -> cp1 (surface point, body-1 frame), n1 (normal there, body-1 frame), d1, p1 = R1 cp1 (world offset)
+//   tail: body-2 side.  -> n (world), p2 (world-frame offset from body 2's origin), pen = -phi_2
 //   stable_io: < 0 on entry = decide which body's normal is used from the two Laplacian probes and report it (0/1);
 //              >= 0 = use that decision (the backward's derivative passes re-use the one of their value pass: the
 //              probes carry no gradient and cost twelve SDF evaluations)
 template <class T>
-__host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const BodyG<T> &b2, const T tri[3][3],
-                                                  const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen,
-                                                  int *stable_io = nullptr)
+__host__ __device__ inline void contact_head(const BodyG<T> &b1, const T tri[3][3], const double abc[3], T *cp1, T *n1, T &d1,
+                                             T *p1)
 {
-    T cp1[3], d1, n1[3], cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
     for (int i = 0; i < 3; ++i) cp1[i] = tri[0][i] * abc[0] + tri[1][i] * abc[1] + tri[2][i] * abc[2];
     // the triangle point is pulled onto body 1's true surface by one Newton step (contacts.py:169-171)
     query_sdf(b1.shape, cp1, d1, n1, true);
     for (int i = 0; i < 3; ++i) cp1[i] = cp1[i] - d1 * n1[i];
     query_sdf(b1.shape, cp1, d1, n1, true);
     quat_apply(b1.q, cp1, p1);
+}
+template <class T>
+__host__ __device__ inline void contact_tail(const BodyG<T> &b1, const BodyG<T> &b2, const T *cp1, const T *n1, const T &d1,
+                                             const T *p1, double lap_h, T *n, T *p2, T &pen, int *stable_io)
+{
+    T cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
     for (int i = 0; i < 3; ++i) { cpw[i] = p1[i] + b1.pos[i]; rel[i] = cpw[i] - b2.pos[i]; }
     quat_apply_inv(b2.q, rel, cp2);
     query_sdf(b2.shape, cp2, d2, n2, true);
@@ -67,6 +73,15 @@ __host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const Body
     for (int i = 0; i < 3; ++i) t[i] = cp2[i] - d2 * n2[i];
     quat_apply(b2.q, t, p2);
     pen = -d2;
+}
+template <class T>
+__host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const BodyG<T> &b2, const T tri[3][3],
+                                                  const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen,
+                                                  int *stable_io = nullptr)
+{
+    T cp1[3], n1[3], d1;
+    contact_head(b1, tri, abc, cp1, n1, d1, p1);
+    contact_tail(b1, b2, cp1, n1, d1, p1, lap_h, n, p2, pen, stable_io);
 }
 
 // ---- time-of-contact distance function (World.H.D, lcp_physics/physics/world.py:150-174) composed with the

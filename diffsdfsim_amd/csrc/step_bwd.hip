@@ -57,7 +57,11 @@ __device__ inline void view_slot(const DssWorld &W, int sc, int k, SlotView &v)
     }
 }
 
-// d(n, p1, p2)/d(pose1, pose2, prm1, prm2) contracted with gbar[9]; out[20]
+// d(n, p1, p2)/d(pose1, pose2, prm1, prm2) contracted with gbar[9]; out[20] = q1(4) x1(3) q2(4) x2(3) prm1(3) prm2(3).
+// Forward-mode duals, four seeds per pass.  Only q1 and prm1 enter the body-1 half of the contact (contact_head: two
+// SDF queries and the Newton step): they take two full passes.  q2, x2 and prm2 enter the body-2 half alone
+// (contact_tail: one query, two rotations), so their three passes differentiate that half with the head as constants;
+// x1 appears only in rel = p1 + x1 - x2, hence d/dx1 = -d/dx2 and needs no pass of its own.
 __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
                             const double *abc, const double *gbar, double *out)
 {
@@ -70,44 +74,80 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     const int mesh = W.mesh_id[(size_t)sc * nb + b1];
     const int voff = W.mesh_voff[mesh], foff = W.mesh_foff[mesh];
     const int *fv = W.faces + (size_t)(foff + face) * 3;
-    int stable = -1;   // decided by the first pass (values are the same in all five), re-used by the others
-    // unrolled: with the group known at compile time the seeds are constants, and (with the finite-math flags this
-    // file is built with, _lib.PER_FILE_FLAGS) the arithmetic on derivative slots that stay zero folds away
+    double tv[3][3], tg[3][3];
+    for (int v = 0; v < 3; ++v)
+        for (int i = 0; i < 3; ++i) { tv[v][i] = W.verts[(size_t)(voff + fv[v]) * 3 + i]; tg[v][i] = W.vgrad[(size_t)(voff + fv[v]) * 3 + i]; }
+    // value pass: the head as constants for the body-2 passes, and the normal-selection decision for all of them
+    int stable = -1;
+    double cp1v[3], n1v[3], d1v, p1v[3];
+    {
+        BodyG<double> B1, B2;
+        for (int i = 0; i < 4; ++i) { B1.q[i] = P1[i]; B2.q[i] = P2[i]; }
+        for (int i = 0; i < 3; ++i) { B1.pos[i] = P1[4 + i]; B2.pos[i] = P2[4 + i]; }
+        make_shape(B1.shape, ty1, prm1);
+        make_shape(B2.shape, ty2, prm2);
+        double nn[3], pp2[3], pen;
+        contact_head(B1, tv, abc, cp1v, n1v, d1v, p1v);
+        contact_tail(B1, B2, cp1v, n1v, d1v, p1v, 1e-3, nn, pp2, pen, &stable);
+    }
+    for (int t = 0; t < 20; ++t) out[t] = 0.0;
+    auto contract = [&](const D *n, const D *p1, const D *p2, int slot0, int cnt) {
+        for (int s = 0; s < cnt; ++s) {
+            double acc = 0.0;
+            for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + (p1 ? gbar[3 + i] * p1[i].d[s] : 0.0) + gbar[6 + i] * p2[i].d[s];
+            out[slot0 + s] = acc;
+        }
+    };
+    // ---- body-1 inputs: full passes, seeds q1 | prm1 -------------------------------------------------------
 #pragma unroll
-    for (int grp = 0; grp < 5; ++grp) {
+    for (int grp = 0; grp < 2; ++grp) {
         BodyG<D> B1, B2;
         D pr1[3], pr2[3];
-        auto seed = [&](int t, double v) {
-            D d(v);
-#pragma unroll
-            for (int sl = 0; sl < N; ++sl) if (sl == t - N * grp) d.d[sl] = 1.0;
-            return d;
-        };
-        for (int i = 0; i < 4; ++i) { B1.q[i] = seed(i, P1[i]); B2.q[i] = seed(7 + i, P2[i]); }
+        for (int i = 0; i < 4; ++i) { B1.q[i] = D(P1[i]); if (grp == 0) B1.q[i].d[i] = 1.0; B2.q[i] = D(P2[i]); }
         for (int i = 0; i < 3; ++i) {
-            B1.pos[i] = seed(4 + i, P1[4 + i]); B2.pos[i] = seed(11 + i, P2[4 + i]);
-            pr1[i] = seed(14 + i, prm1[i]); pr2[i] = seed(17 + i, prm2[i]);
+            B1.pos[i] = D(P1[4 + i]); B2.pos[i] = D(P2[4 + i]);
+            pr1[i] = D(prm1[i]); if (grp == 1) pr1[i].d[i] = 1.0;
+            pr2[i] = D(prm2[i]);
         }
         make_shape(B1.shape, ty1, pr1);
         make_shape(B2.shape, ty2, pr2);
         D tri[3][3];
         for (int v = 0; v < 3; ++v)
             for (int i = 0; i < 3; ++i) {
-                const double val0 = W.verts[(size_t)(voff + fv[v]) * 3 + i], gr = W.vgrad[(size_t)(voff + fv[v]) * 3 + i];
-                D d(val0);
-                // box: own axis; sphere: radius; cylinder: x,y <- rad, z <- height
-                const int t = (ty1 == SHAPE_BOX) ? 14 + i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 15 : 14), s = t - N * grp;
+                D d(tv[v][i]);
+                if (grp == 1) {
+                    // box: own axis; sphere: radius; cylinder: x,y <- rad, z <- height
+                    const int s = (ty1 == SHAPE_BOX) ? i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 1 : 0);
 #pragma unroll
-                for (int sl = 0; sl < N; ++sl) if (sl == s) d.d[sl] = gr;   // selects: a run-time index would put d in scratch
+                    for (int sl = 0; sl < 3; ++sl) if (sl == s) d.d[sl] = tg[v][i];   // selects: a run-time index would put d in scratch
+                }
                 tri[v][i] = d;
             }
         D n[3], p1[3], p2[3], pen;
         contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable);
-        for (int s = 0; s < N; ++s) {
-            double acc = 0.0;
-            for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + gbar[3 + i] * p1[i].d[s] + gbar[6 + i] * p2[i].d[s];
-            out[N * grp + s] = acc;
+        if (grp == 0) contract(n, p1, p2, 0, 4);
+        else contract(n, p1, p2, 14, 3);
+    }
+    // ---- body-2 inputs: the tail alone, seeds q2 | x2 | prm2 -----------------------------------------------
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp) {
+        BodyG<D> B1, B2;
+        D pr1[3], pr2[3];
+        for (int i = 0; i < 4; ++i) { B1.q[i] = D(P1[i]); B2.q[i] = D(P2[i]); if (grp == 0) B2.q[i].d[i] = 1.0; }
+        for (int i = 0; i < 3; ++i) {
+            B1.pos[i] = D(P1[4 + i]);
+            B2.pos[i] = D(P2[4 + i]); if (grp == 1) B2.pos[i].d[i] = 1.0;
+            pr1[i] = D(prm1[i]);
+            pr2[i] = D(prm2[i]); if (grp == 2) pr2[i].d[i] = 1.0;
         }
+        make_shape(B1.shape, ty1, pr1);
+        make_shape(B2.shape, ty2, pr2);
+        D cp1[3], n1[3], d1(d1v), p1[3], n[3], p2[3], pen;
+        for (int i = 0; i < 3; ++i) { cp1[i] = D(cp1v[i]); n1[i] = D(n1v[i]); p1[i] = D(p1v[i]); }
+        contact_tail(B1, B2, cp1, n1, d1, p1, 1e-3, n, p2, pen, &stable);
+        if (grp == 0) contract(n, nullptr, p2, 7, 4);
+        else if (grp == 1) { contract(n, nullptr, p2, 11, 3); for (int i = 0; i < 3; ++i) out[4 + i] = -out[11 + i]; }
+        else contract(n, nullptr, p2, 17, 3);
     }
 }
 
