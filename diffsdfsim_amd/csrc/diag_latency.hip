@@ -1,4 +1,4 @@
-// diag_latency.hip -- diagnostic micro-benchmarks (compiled to nothing unless -DDSS_DIAG; tools_latency.py).
+// diag_latency.hip -- diagnostic micro-benchmarks (compiled to nothing unless -DDSS_DIAG; tools/latency.py).
 // One wavefront per SIMD is how the LCP kernel runs, so the raw dependent-issue latencies of gfx950 matter.
 #include "dss_device.h"
 #if defined(DSS_DIAG) && !defined(DSS_EMU)

@@ -30,7 +30,7 @@
 #include "kkt_reg.h"
 #include "wave_utils.h"
 
-#if defined(DSS_DIAG)   // diagnostic build only (tools_lcp_phases.py); the product library has no global state
+#if defined(DSS_DIAG)   // diagnostic build only (tools/lcp_phases.py); the product library has no global state
 __device__ long long *g_lcp_stamps = nullptr;
 #define LSTAMP(i) do { if (g_lcp_stamps && threadIdx.x == 0) atomicAdd((unsigned long long *)&g_lcp_stamps[(size_t)blockIdx.x * 16 + (i)], (unsigned long long)(wall_clock64() - t_last)); t_last = wall_clock64(); } while (0)
 #define LSTAMP_INIT long long t_last = wall_clock64()

@@ -1,7 +1,7 @@
 """Dev aid: time dss_igr_query (fp64 MFMA IGR MLP) on a 128^3 grid; report TFLOP/s against the fp64 matrix peak."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffsdfsim_amd.igr import igr_query, pack_weights
 from oracle import igr_oracle as IO
 

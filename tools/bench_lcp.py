@@ -1,4 +1,6 @@
 """Micro-benchmark of the two LCP kernels (development aid; bench.py is the contract benchmark)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, "tests")

@@ -1,7 +1,7 @@
 """Dev aid: world-construction operators at the reference's 128^3 resolution (grid SDF, marching cubes, mesh inertia)."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffsdfsim_amd.mass_properties import sdf_query, mesh_inertia
 from diffsdfsim_amd.meshsdf import marching_cubes, _grid
 

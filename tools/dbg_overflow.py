@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from diffsdfsim_amd import scenes
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend

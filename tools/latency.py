@@ -1,4 +1,6 @@
 """Dev aid: raw dependent-issue latencies of gfx950 for one wavefront per SIMD (needs the -DDSS_DIAG build)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes, glob, os, subprocess, sys
 import numpy as np, torch
 from diffsdfsim_amd import _lib

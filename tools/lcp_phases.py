@@ -1,4 +1,6 @@
 """Diagnostic: phase shares of lcp_contact_forward_kernel (needs the -DDSS_DIAG build: tools only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes, glob, os, subprocess, sys
 import numpy as np, torch
 from diffsdfsim_amd import _lib, scenes

@@ -1,5 +1,6 @@
 """Dev aid: distribution of IPM iterations / contacts per scene in the bench workload (how much of the LCP launch is tail)."""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from diffsdfsim_amd import scenes
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend
