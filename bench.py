@@ -95,11 +95,17 @@ def main():
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl" on ROCm) over xGMI on a real node; DSS_DIST_BACKEND=gloo rehearses the same code path with
+        # several ranks sharing one GPU (collectives then go through host copies)
+        backend = os.environ.get("DSS_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
+        backend = None
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if backend == "gloo" else dev      # where collective buffers live
 
     from diffsdfsim_amd import _lib, scenes
     from diffsdfsim_amd.engine import BatchEngine, TorchBackend
@@ -174,14 +180,15 @@ def main():
     E.backward_sweep(att)
     final = E.arr["pose"].clone()
     if dist is not None:   # "final trivial gather" of the shard results
-        out = [torch.empty_like(final) for _ in range(world)]
-        dist.all_gather(out, final)
+        fin = final.to(cdev)
+        out = [torch.empty_like(fin) for _ in range(world)]
+        dist.all_gather(out, fin)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
