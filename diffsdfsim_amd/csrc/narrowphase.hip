@@ -231,8 +231,27 @@ template <class G> __device__ inline int compact_slot(int flag, int &count, Scra
 }
 
 // block arg-min over (key, index) with lowest index on ties; returns the index (or -1 if none valid)
+// value of lane 0, for every lane (the xor butterfly leaves the same set summed in every lane, but only lane 0's
+// order of additions is that of the LDS tree the workgroup flavour uses)
+__device__ inline double wave_first(double x)
+{
+#if defined(DSS_EMU)
+    return __shfl(x, 0, 64);
+#else
+    return dss_uniform(x);
+#endif
+}
 template <class G> __device__ inline int block_argmin(double key, int idx, ScratchT<G> &S)
 {
+    if (G::BT == 64) {   // one wavefront: shuffles, no LDS round trips; (key, index) minimum is order independent
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ok = __shfl_xor(key, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (oi >= 0 && (idx < 0 || ok < key || (ok == key && oi < idx))) { key = ok; idx = oi; }
+        }
+        return idx;
+    }
     const int tid = G::tid();
     S.red_d[tid] = key; S.red_i[tid] = idx;
     G::sync();
@@ -250,6 +269,7 @@ template <class G> __device__ inline int block_argmin(double key, int idx, Scrat
 }
 template <class G> __device__ inline double block_max(double v, ScratchT<G> &S)
 {
+    if (G::BT == 64) return wave_max_dpp(v);
     const int tid = G::tid();
     S.red_d[tid] = v;
     G::sync();
@@ -260,6 +280,7 @@ template <class G> __device__ inline double block_max(double v, ScratchT<G> &S)
 }
 template <class G> __device__ inline double block_sum(double v, ScratchT<G> &S)
 {
+    if (G::BT == 64) return wave_first(wave_sum(v));   // same association as the tree below, bit for bit
     const int tid = G::tid();
     S.red_d[tid] = v;
     G::sync();
@@ -412,7 +433,10 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
                 if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
                 if (best < 0) { best = k; bx = qx; by = qy; continue; }
                 const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
-                if (cr < -1e-9 * sqrt(lb * lq) || (fabs(cr) <= 1e-9 * sqrt(lb * lq) && lq > lb)) { best = k; bx = qx; by = qy; }
+                // clockwise of the best so far by more than the angular tolerance (|sin| > 1e-9, compared squared), or
+                // collinear with it and farther
+                const double c2 = cr * cr, t2 = 1e-18 * (lb * lq);
+                if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && lq > lb)) { best = k; bx = qx; by = qy; }
             }
             S.red_i[tid] = best;
             G::sync();
@@ -425,7 +449,8 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
                             const double ax = S.hp[3 * a + c0] - cx, ay = S.hp[3 * a + c1] - cy;
                             const double qx = S.hp[3 * b + c0] - cx, qy = S.hp[3 * b + c1] - cy;
                             const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
-                            if (cr < -1e-9 * sqrt(la * lq) || (fabs(cr) <= 1e-9 * sqrt(la * lq) && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
+                            const double c2 = cr * cr, t2 = 1e-18 * (la * lq);
+                            if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
                         }
                     }
                 }

@@ -1,6 +1,7 @@
 """Diagnostic: per-phase time of narrowphase_kernel workgroups (wall_clock64 stamps, 100 MHz)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import numpy as np, torch
 from diffsdfsim_amd import scenes
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend
