@@ -62,4 +62,38 @@ template <int N> __device__ __forceinline__ double regk_solve_natural(const RegK
     return res;
 }
 
+// The same on the leading M x M part of the register array (M <= N): used when a body is pinned by identity
+// equality rows, which removes its six rows and the six multiplier rows from the system to factor (lcp_contact.hip).
+template <int N, int M> __device__ __forceinline__ void regk_factor_lead(RegK<N> &R)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        const double inv = 1.0 / wave_bcast(R.a[k], k);
+        const bool upd = lane > k && lane < M;
+        const double l = upd ? R.a[k] * inv : 0.0;
+        if (upd) R.a[k] = l;
+        if (lane == k) R.a[k] = inv;
+#pragma unroll
+        for (int j = k + 1; j < M; ++j) R.a[j] -= l * wave_bcast(R.a[j], k);
+    }
+}
+template <int N, int M> __device__ __forceinline__ double regk_solve_lead(const RegK<N> &R, double x)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        const double bk = wave_bcast(x, k);
+        if (lane > k && lane < M) x -= R.a[k] * bk;
+    }
+    double res = 0.0;
+#pragma unroll
+    for (int k = M - 1; k >= 0; --k) {
+        const double xk = wave_bcast(x, k) * wave_bcast(R.a[k], k);
+        if (lane == k) res = xk;
+        if (lane < k) x -= R.a[k] * xk;
+    }
+    return res;
+}
+
 }  // namespace dss

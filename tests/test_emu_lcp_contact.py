@@ -11,9 +11,15 @@ from oracle import lcp_oracle as O
 @pytest.mark.parametrize("cfg", [dict(seed=1, B=3, nb=2, maxc=8, fd=8), dict(seed=2, B=2, nb=4, maxc=16, fd=8),
                                  dict(seed=3, B=2, nb=3, maxc=8, fd=4), dict(seed=4, B=1, nb=3, maxc=80, fd=8, nc_lo=70),
                                  dict(seed=6, B=2, nb=8, maxc=24, fd=8, nc_lo=10),
-                                 dict(seed=7, B=1, nb=3, maxc=136, fd=8, nc_lo=100)])   # > 128: the streaming kernel
+                                 dict(seed=7, B=1, nb=3, maxc=136, fd=8, nc_lo=100),   # > 128: the streaming kernel
+                                 dict(seed=8, B=1, nb=8, maxc=16, fd=8, nc_lo=8, rot_A=True)])   # equality rows that are not the identity: the unreduced KKT system
 def test_contact_lcp_forward_backward_vs_dense_oracle(cfg):
+    cfg = dict(cfg)
+    rot_A = cfg.pop("rot_A", False)
     P = S.random_problem(**cfg)
+    if rot_A:   # body 0 still pinned, but by a rotated set of rows: the pinned-body shortcut must not trigger
+        Qr, _ = np.linalg.qr(np.random.default_rng(77).standard_normal((6, 6)))
+        P["A"][:, :, :6] = Qr
     x, lam, slack, nu, it, st = emu.lcp_contact_forward(P, max_iter=10)
     dl = np.random.default_rng(9).standard_normal(x.shape)
     dM, dp, dcop, dA, db = emu.lcp_contact_backward(P, x, lam, slack, nu, dl)

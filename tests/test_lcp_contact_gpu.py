@@ -32,11 +32,17 @@ def run(P, max_iter=10):
 @pytest.mark.parametrize("cfg", [dict(seed=11, B=6, nb=2, maxc=8, fd=8), dict(seed=12, B=4, nb=8, maxc=32, fd=8),
                                  dict(seed=13, B=3, nb=3, maxc=8, fd=4), dict(seed=14, B=2, nb=4, maxc=96, fd=8, nc_lo=70),
                                  dict(seed=15, B=5, nb=2, maxc=8, fd=8), dict(seed=16, B=3, nb=8, maxc=24, fd=8, nc_lo=10),
-                                 dict(seed=17, B=2, nb=3, maxc=136, fd=8, nc_lo=100)])   # > 128: the streaming kernel
+                                 dict(seed=17, B=2, nb=3, maxc=136, fd=8, nc_lo=100),   # > 128: the streaming kernel
+                                 dict(seed=18, B=2, nb=8, maxc=24, fd=8, nc_lo=10, rot_A=True), dict(seed=19, B=2, nb=2, maxc=8, fd=8, rot_A=True)])   # equality rows that are not the identity: the unreduced KKT system
 def test_forward_backward_vs_dense_oracle(cfg):
     from diffsdfsim_amd.lcp.contact import lcp_contact_backward
     from oracle import lcp_oracle as O
+    cfg = dict(cfg)
+    rot_A = cfg.pop("rot_A", False)
     P = S.random_problem(**cfg)
+    if rot_A:   # body 0 still pinned, but by a rotated set of rows: the pinned-body shortcut must not trigger
+        Qr, _ = np.linalg.qr(np.random.default_rng(77).standard_normal((6, 6)))
+        P["A"][:, :, :6] = Qr
     d, (x, lam, slack, nu, it, st) = run(P)
     dl = torch.tensor(np.random.default_rng(9).standard_normal(tuple(x.shape)), device="cuda")
     dM, dp, dcop, dA, db = lcp_contact_backward(d["Mblk"], d["A"], d["cop"], d["cbody"], d["nc"], P["fd"], x, lam, slack, nu, dl, want_dA=True)
