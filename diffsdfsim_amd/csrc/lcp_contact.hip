@@ -1,5 +1,5 @@
-// lcp_contact.hip -- contact-structured frictional LCP for gfx950: one wavefront per scene,
-// the whole KKT factor/solve in LDS.
+// lcp_contact.hip -- contact-structured frictional LCP for gfx950: one wavefront per scene, the reduced KKT
+// system factored and solved in registers.
 //
 // Solves exactly the mixed LCP the reference's PdipmEngine assembles (engines.py:56-81) with the
 // same predictor-corrector iteration as the reference solver (batch.py:70-231), but never builds
@@ -18,12 +18,14 @@
 // with a 3x3 matrix C_c per contact.  The two are the same Newton system, so the iterates agree
 // with the reference to rounding (verified against its goldens: 1e-13 on the velocities).
 //
-// Mapping: blockDim = 64 (one wave) per scene.  LDS: K (n x n, odd leading dimension => conflict
-// free column walks), contact points, per-contact 3-vectors / C matrices, nz-sized vectors.
-// Per-contact IPM state (s, z, rz, ds, dz: NR doubles each) streams through an L2-resident
-// workspace in [row][contact] order so lane = contact loads are coalesced.  All cross-contact
-// sums are ordered (per-body contact lists, sequential K accumulation): results are bitwise
-// reproducible run to run.
+// Mapping: blockDim = 64 (one wave) per scene.  LDS: H = Q + sum P C P^T (odd leading dimension => conflict free
+// column walks), contact points, per-contact 3-vectors / C matrices, nz-sized vectors.  The compiled system sizes
+// (n = 54: 8 bodies + 6 equality rows; n = 18) are factored with one matrix row per lane in registers (kkt_reg.h);
+// a body pinned by identity equality rows is eliminated in closed form first.  With maxc <= 128 the per-contact IPM
+// state (s, z, rz, ds, dz, d: NR doubles each) of two contacts per lane lives in registers
+// (lcp_contact_forward_reg_kernel); beyond that it streams through an L2-resident workspace in [row][contact] order
+// (lcp_contact_forward_kernel); any other n <= 64 falls back to an LU in LDS.  All cross-contact sums are ordered
+// (per-body contact lists, sequential K accumulation): results are bitwise reproducible run to run.
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"

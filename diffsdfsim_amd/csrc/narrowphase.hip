@@ -6,11 +6,12 @@
 //                       _compute_contacts                contacts.py:161-214
 //                       _filter_contacts                 contacts.py:97-158
 //   compact_kernel      the order in which the callbacks append to world.contacts
-// One 256-thread workgroup owns one (scene, directed body pair a->b): the triangles of a's mesh
+// One group of threads owns one (scene, directed body pair a->b) -- a single wavefront when a's mesh is small, a
+// 256-thread workgroup for big meshes (see Group below): the triangles of a's mesh
 // are searched against b's SDF.  Pair order is canonical (i<j, then i->j before j->i), standing
 // in for ODE's unreproducible HashSpace callback order.  Everything that the
 // reference decides over the whole candidate set of a pair (early exits of the Frank-Wolfe loop,
-// the "all penetrations <= tol" test, greedy normal clustering) is decided over the workgroup.
+// the "all penetrations <= tol" test, greedy normal clustering) is decided over the group.
 // Candidate and contact lists are compacted in ascending face order with ballot prefix sums, so
 // results are deterministic and cluster seeds match the reference's.
 //
@@ -1066,7 +1067,7 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
     (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // {count, cursor} x {block, wave, deferred}
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(NT), 0, stream, W);
-    // 256 CUs x 3 resident workgroups (145 VGPRs) walk the compact list; no idle dispatches
+    // 256 CUs x DSS_NP_WAVES resident workgroups walk the work lists; no idle dispatches
     const int grid = np_grid(W.B, W.nb);
     hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);
     hipLaunchKernelGGL(narrowphase_kernel<true>, dim3(grid), dim3(NT), 0, stream, W);   // normally finds an empty list

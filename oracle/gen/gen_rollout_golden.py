@@ -119,6 +119,8 @@ def main():
     run("rollout_stack2", lambda: scenes.box_stack(nbox=2, seed=4, vel_scale=0.5, push=1.5), nsteps=3)
     run("rollout_boxdrop", lambda: scenes.box_drop(seed=7), nsteps=12)
     run("rollout_cylinder", lambda: scenes.cylinder_drop(seed=9), nsteps=10)
+    # long horizon: 100 outer steps, 245 sub-steps, several bounces with time-of-contact events, coming to rest
+    run("rollout_sphere_long", lambda: scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0)), nsteps=100)
 
 
 if __name__ == "__main__":

@@ -25,9 +25,9 @@ def test_initial_contacts_match_reference(name):
         R.check_contacts(E, s, g["init_body"], g["init_geom"], len(g["init_body"]))
 
 
-@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere", 24, 5), ("rollout_stack1", 4, 4), ("rollout_stack2", 3, 130), ("rollout_boxdrop", 12, 3), ("rollout_cylinder", 10, 3)])
+@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere", 24, 5), ("rollout_stack1", 4, 4), ("rollout_stack2", 3, 130), ("rollout_boxdrop", 12, 3), ("rollout_cylinder", 10, 3), ("rollout_sphere_long", 100, 2)])
 def test_rollout_matches_reference(name, nsteps, copies):
-    g, E = make(name, copies, max_sub=64)
+    g, E = make(name, copies, max_sub=320)
     for _ in range(nsteps):
         E.step()
     nsub = E.get("nsub")
@@ -46,11 +46,11 @@ def test_rollout_matches_reference(name, nsteps, copies):
         assert np.abs(tp[j, 0] - g["traj_p"][j - 1]).max() < 1e-8
 
 
-@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere_notoc", 24, 3), ("rollout_sphere", 24, 3), ("rollout_stack1", 4, 2), ("rollout_stack2", 3, 65), ("rollout_boxdrop", 12, 2), ("rollout_cylinder", 10, 2)])
+@pytest.mark.parametrize("name,nsteps,copies", [("rollout_sphere_notoc", 24, 3), ("rollout_sphere", 24, 3), ("rollout_stack1", 4, 2), ("rollout_stack2", 3, 65), ("rollout_boxdrop", 12, 2), ("rollout_cylinder", 10, 2), ("rollout_sphere_long", 100, 2)])
 def test_gradients_match_reference_autograd(name, nsteps, copies):
     """Reverse sweep (csrc/step_bwd.hip) vs torch.autograd of the reference: d sum|pos_T|^2 / d(dims | radius).
     Flat-on-flat contacts make the reference gradient bimodal (both branches are in the golden)."""
-    g, E = make(name, copies, max_sub=64)
+    g, E = make(name, copies, max_sub=320)
     R.rollout_and_sweep(E, nsteps)
     for s in (0, copies - 1):
         R.check_gradients(E, g, tol=1e-3 if name == "rollout_stack2" else 1e-4, s=s)
