@@ -1070,7 +1070,8 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
     // 256 CUs x DSS_NP_WAVES resident workgroups walk the work lists; no idle dispatches
     const int grid = np_grid(W.B, W.nb);
     hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);
-    hipLaunchKernelGGL(narrowphase_kernel<true>, dim3(grid), dim3(NT), 0, stream, W);   // normally finds an empty list
+    // normally finds an empty list: a small grid keeps the empty launch cheap, and works a real list off all the same
+    hipLaunchKernelGGL(narrowphase_kernel<true>, dim3(grid < 64 ? grid : 64), dim3(NT), 0, stream, W);
     hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }

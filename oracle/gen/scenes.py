@@ -95,3 +95,18 @@ def cylinder_drop(seed=0, floor_dims=(4.0, 1.0, 4.0), mu=0.4, rest=0.3, requires
     c = SDFCylinder(pos, rad, height, vel=vel, custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
     c.add_force(Gravity3D())
     return [floor, c], [TotalConstraint3D(floor)], [rad, height]
+
+
+def big_box(requires_grad=True, gap=5e-4, mu=0.5, rest=0.0):
+    """A wide flat box on the floor: ~800 contact candidates on its bottom face -- more than the wavefront-sized
+    scratch of the narrow phase holds, so the pair is worked off by the deferred (workgroup) path."""
+    from sdf_physics.physics3d.bodies import SDFBox
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+
+    floor = SDFBox([0, -0.5, 0], [6.0, 1.0, 6.0], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    dims = torch.tensor([1.9, 0.5, 1.9], dtype=torch.double, requires_grad=requires_grad)
+    pos = torch.tensor([0, 0.1, 0, 0.03, gap + 0.25, -0.02], dtype=torch.double)
+    b = SDFBox(pos, dims, vel=[0, 0, 0, 0.6, -0.1, 0.2], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    b.add_force(Gravity3D())
+    return [floor, b], [TotalConstraint3D(floor)], [dims]

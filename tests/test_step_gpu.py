@@ -56,3 +56,18 @@ def test_gradients_match_reference_autograd(name, nsteps, copies):
         R.check_gradients(E, g, tol=1e-3 if name == "rollout_stack2" else 1e-4, s=s)
     gp = E.be.to_numpy(E.adj["g_prm"])
     assert (gp == gp[:1]).all(), "replicated scenes must give identical gradients"
+
+
+def test_pair_that_outgrows_the_wavefront_scratch_matches_reference():
+    """A wide flat box on the floor has ~800 contacts before thinning: the wavefront that starts the pair hands it
+    to the deferred list, a whole workgroup redoes it.  Same contacts, same trajectory as the reference."""
+    g, E = make("rollout_bigbox", 2, max_sub=16, max_cand=2048, maxc=64)
+    for _ in range(3):
+        E.step()
+    assert int(E.get("n_pairs")[4]) >= 1, "the pair was expected to be deferred"
+    assert int(E.get("overflow").max()) == 0
+    k = len(g["traj_t"]) - 1
+    assert (E.get("nsub") == len(g["traj_t"])).all()
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
+    for s in (0, 1):
+        R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
