@@ -1063,7 +1063,11 @@ static inline int np_grid(int B, int nb)
 int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
                          double *geom_out, hipStream_t stream)
 {
-    if (W.max_cand > NT * MAX_CPT || W.nb < 2) return DSS_E_UNSUPPORTED;
+    if (W.max_cand > NT * MAX_CPT || W.nb < 1) return DSS_E_UNSUPPORTED;
+    if (W.nb < 2) {   // a single body has nothing to collide with: empty contact lists (the no-contact branch, engines.py:40-54)
+        hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
+        return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+    }
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
     (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // {count, cursor} x {block, wave, deferred}
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(NT), 0, stream, W);

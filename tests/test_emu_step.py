@@ -28,3 +28,24 @@ def test_rollout_matches_reference(name, nsteps):
     assert np.abs(E.get("pose")[0] - g["traj_p"][k_ref]).max() < 1e-7
     assert np.abs(E.get("vel")[0] - g["traj_v"][k_ref]).max() < 1e-7
     R.check_contacts(E, 0, g["traj_body"][k_ref], g["traj_geom"][k_ref], int(g["traj_nc"][k_ref]))
+
+
+def test_single_body_contact_free_branch_matches_reference():
+    """One body, translation locked by three equality rows, constant torque, no contacts (engines.py:40-54;
+    golden: oracle/gen/gen_config5_golden.py).  The torque of the golden is on for t < 0.3 = the first 9 steps."""
+    import os
+    from diffsdfsim_amd import meshes
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "config5_spin.npz"))
+    dims = g["dims"]
+    v, f, tie = meshes.box_mesh(dims)
+    I = float(g["mass"]) * np.diag([dims[1] ** 2 + dims[2] ** 2, dims[0] ** 2 + dims[2] ** 2, dims[0] ** 2 + dims[1] ** 2]) / 12
+    one = lambda a: np.asarray(a, np.float64)[None, None]
+    spec = dict(pose=one([1.0, 0, 0, 0, 0, 0, 0]), vel=one(np.zeros(6)), mass=np.full((1, 1), float(g["mass"])), inertia=I[None, None],
+                restitution=np.zeros((1, 1)), fric=np.zeros((1, 1)), fext=one(np.concatenate([float(g["mag"]) * g["dir"], np.zeros(3)])),
+                shape_type=np.zeros((1, 1), np.int32), shape_prm=one(dims), mesh_id=np.zeros((1, 1), np.int32), meshes=[(v, f)],
+                mesh_vgrad=[0.5 * tie], Je=np.concatenate([np.zeros((3, 3)), np.eye(3)], 1)[None], no_contact=np.zeros((1, 1), np.uint8))
+    E = BatchEngine(spec, backend=emu.EmuBackend(), max_sub=16, dt=float(g["dt"]))
+    for k in range(9):
+        E.step()
+        assert np.abs(E.get("pose")[0, 0] - g["traj_p"][k]).max() < 1e-10 and np.abs(E.get("vel")[0, 0] - g["traj_v"][k]).max() < 1e-10
+    assert (E.get("nc") == 0).all()
