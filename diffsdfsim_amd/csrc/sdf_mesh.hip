@@ -118,9 +118,47 @@ __global__ void __launch_bounds__(256) mesh_inertia_kernel(const double *verts, 
     }
 }
 
+// self-test of geom.h's shared-reciprocal triple division against three IEEE divisions (bit patterns compared)
+__global__ void __launch_bounds__(256) div3_selftest_kernel(const double *num, const double *den, int n, int *mismatches)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double a[3] = {num[3 * (size_t)i], num[3 * (size_t)i + 1], num[3 * (size_t)i + 2]}, d = den[i];
+    double q[3];
+    div3(a, d, q);
+    int bad = 0;
+    for (int k = 0; k < 3; ++k) {
+        volatile double ref = a[k] / d;       // volatile: keep it a plain division
+        bad += __double_as_longlong(q[k]) != __double_as_longlong((double)ref);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+__global__ void __launch_bounds__(256) sqrt_selftest_kernel(const double *x, int n, int *mismatches)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    volatile double ref = sqrt(x[i]);
+    if (__double_as_longlong(t_sqrt(x[i])) != __double_as_longlong((double)ref)) atomicAdd(mismatches, 1);
+}
+
 }  // namespace
 
 extern "C" {
+
+int dss_selftest_sqrt(const double *x, int n, int *mismatches, void *stream)
+{
+    if (!x || !mismatches || n <= 0) return DSS_E_BADARG;
+    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n, mismatches);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+int dss_selftest_div3(const double *num, const double *den, int n, int *mismatches, void *stream)
+{
+    if (!num || !den || !mismatches || n <= 0) return DSS_E_BADARG;
+    hipLaunchKernelGGL(div3_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, num, den, n, mismatches);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
 
 int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, double *sdf, double *grad,
                   unsigned char *overlap_mask, void *stream)

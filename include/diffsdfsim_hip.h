@@ -268,6 +268,12 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
 int dss_mesh_inertia(const double *verts, const int *faces, const int *mesh_voff, const int *mesh_foff, const int *mesh_nf,
                      int nmesh, const double *mass, double *J, double *volume, void *stream);
 
+/* Self-test of the shared-reciprocal triple division the geometry kernels use (csrc/geom.h: div3): counts the
+ * quotients num[i][k] / den[i] whose bit pattern differs from an IEEE division on the device. */
+int dss_selftest_div3(const double *num, const double *den, int n, int *mismatches, void *stream);
+/* The same for the unscaled square root (csrc/geom.h: t_sqrt) against sqrt() on the device. */
+int dss_selftest_sqrt(const double *x, int n, int *mismatches, void *stream);
+
 /* Marching cubes + MeshSDF backward: replaces SDF3D._diff_marching_cubes (bodies.py:653-704).
  *   phi [n0][n1][n2] SDF samples (x slowest, as torch.meshgrid(...).reshape(res,res,res)); inside <=> phi < iso.
  *   ntri_tab [256], tri_tab [256][max_tri][3] (cube-edge ids): diffsdfsim_amd/mc_tables.py.

@@ -59,3 +59,32 @@ def test_batched_mesh_table():
     J = mesh_inertia([g[n + "_verts"] for n in names], [g[n + "_faces"] for n in names], [2.5] * 3)
     for k, n in enumerate(names):
         assert np.abs(J[k].cpu().numpy() - g[n + "_J"]).max() < 1e-11 * np.abs(g[n + "_J"]).max()
+
+
+def test_shared_reciprocal_division_is_bit_identical_to_ieee_division():
+    """geom.h div3 (one reciprocal refinement for three quotients) vs three `/` on the device, over the magnitudes
+    the geometry kernels see (lengths down to the 1e-12 clamp, coordinates up to 1e3) and well beyond."""
+    from diffsdfsim_amd import _lib
+    r = np.random.default_rng(5)
+    n = 1 << 21
+    num = r.standard_normal((n, 3)) * 10.0 ** r.uniform(-15, 6, (n, 1))
+    den = np.abs(r.standard_normal(n)) * 10.0 ** r.uniform(-13, 6, n) + 1e-300
+    num[:1000] = 0.0; den[1000:2000] = 1e-12; den[2000:3000] = 3.0; num[3000:4000] = den[3000:4000, None]
+    tn, td = torch.tensor(num, device="cuda"), torch.tensor(den, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().dss_selftest_div3(_lib.ptr(tn), _lib.ptr(td), n, _lib.ptr(bad), _lib.stream_ptr(tn.device)), "dss_selftest_div3")
+    assert int(bad.item()) == 0
+
+
+def test_unscaled_square_root_is_bit_identical_to_sqrt():
+    from diffsdfsim_amd import _lib
+    r = np.random.default_rng(6)
+    n = 1 << 22
+    x = np.abs(r.standard_normal(n)) * 10.0 ** r.uniform(-40, 12, n)
+    x[:1000] = 0.0
+    x[1000:2000] = np.arange(1000.0) ** 2
+    x[2000:3000] = np.nextafter(np.arange(1.0, 1001.0) ** 2, 0)
+    tx = torch.tensor(x, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().dss_selftest_sqrt(_lib.ptr(tx), n, _lib.ptr(bad), _lib.stream_ptr(tx.device)), "dss_selftest_sqrt")
+    assert int(bad.item()) == 0
