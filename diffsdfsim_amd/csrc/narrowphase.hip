@@ -556,11 +556,11 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         const bool in_cube = query_sdf(Bd.g.shape, x, phi, g, !box);
         for (int k = 0; k < 3; ++k) {
             const double d[3] = {x[0] - pqr[k][0], x[1] - pqr[k][1], x[2] - pqr[k][2]};
-            const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const double r = t_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             if (r > rad) rad = r;
         }
         if (box) return (phi < rad + W.eps) && in_cube;
-        const double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        const double gn = t_sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
     auto test_face = [&](int f, double pqr[3][3]) -> int {
@@ -869,7 +869,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         auto get_state = [&](int k) -> int { return lds_state ? (int)S.cst[k] : cstate[k]; };
         auto set_state = [&](int k, int v) { if (lds_state) S.cst[k] = (unsigned char)v; else cstate[k] = v; };
         for (int k = tid; k < ncon; k += G::BT) {
-            const double nn = sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
+            const double nn = t_sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
             set_state(k, nn > 1e-12 ? 0 : 255);
         }
         G::sync();
