@@ -760,6 +760,42 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (nmov > G::HCAP) { if (G::BT == 64) return 1; over |= 2; nmov = G::HCAP; }
         G::sync();
     }
+    if (G::BT == 64 && nmov > 0 && nmov <= 16) {
+        // Few movers, one wavefront: the loop is a serial chain (evaluate -> pick a vertex -> move -> evaluate ...)
+        // on a handful of lanes.  The step size of iteration k is known in advance (2 / (k + 2), float32), so the
+        // point after the move is one of three: four lanes per mover evaluate the current point (role 0) and the
+        // three possible next points (roles 1-3) at once, and every evaluation latency advances TWO iterations.
+        // The arithmetic of each iteration is the sequential one, bit for bit.
+        const int mi = tid >> 2, role = tid & 3, qbase = tid & ~3;
+        Cand m0;
+        const int k0 = mi < nmov ? S.hidx[mi] : -1;
+        int alive = k0 >= 0;
+        if (alive) load_c(m0, k0);
+        for (int iter = 1; iter < 32; iter += 2) {
+            Cand e = m0;
+            if (role) apply_c(e, (float)(2.0 / (iter + 2.0)), role - 1);
+            float gm = 0.0f; int bi = 0, pen = 0;
+            if (alive) eval_c(e, role ? iter + 1 : iter, gm, bi, pen);
+            // iteration `iter`: what role 0 found at the current point
+            const float gmA = __shfl(gm, qbase, 64);
+            const int biA = __shfl(bi, qbase, 64), penA = __shfl(pen, qbase, 64);
+            const unsigned long long bmA = __ballot(alive && gmA != 0.0f), bpA = __ballot(alive && penA);
+            if (gmA == 0.0f) alive = 0;                      // froze: x no longer changes
+            if (bmA == 0ull || bpA != 0ull) break;           // all gamma == 0, or a penetrating point (contacts.py:74-77)
+            if (alive) apply_c(m0, gmA, biA);
+            if (iter + 1 >= 32) break;
+            // iteration `iter + 1`: what the lane that evaluated the point just moved to found there
+            const int src = qbase + 1 + biA;
+            const float gmB = __shfl(gm, src, 64);
+            const int biB = __shfl(bi, src, 64), penB = __shfl(pen, src, 64);
+            const unsigned long long bmB = __ballot(alive && gmB != 0.0f), bpB = __ballot(alive && penB);
+            if (gmB == 0.0f) alive = 0;
+            if (bmB == 0ull || bpB != 0ull) break;
+            if (alive) apply_c(m0, gmB, biB);
+        }
+        if (k0 >= 0 && role == 0) store_c(m0, k0);
+        nmov = 0;     // the general loop below has nothing left to do
+    }
     // the mover owned by this thread (if any) stays in registers for the remaining iterations
     Cand m0;
     const int k0 = tid < nmov ? S.hidx[tid] : -1;
