@@ -892,6 +892,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     STAMP(4);
     // ---- 5. filter: greedy normal clusters, hull of each (contacts.py:97-158) -------------------
     int nkeep = 0;
+    unsigned keptbits = 0u;
     if (ncon <= 1) {
         if (tid == 0) cstate[0] = -2;  // kept
         nkeep = ncon;
@@ -939,9 +940,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) set_state(S.hidx[j], 2);
             G::sync();
         }
-        for (int k = tid; k < ncon; k += G::BT) {
+        for (int k = tid, r = 0; k < ncon; k += G::BT, ++r) {
             const int kept = get_state(k) == 2;
-            cstate[k] = kept ? -2 : 0;     // the final stage reads the global array
+            keptbits |= (unsigned)kept << r;     // round r of this thread: the final stage walks the same (round, thread) grid
             nkeep += kept;
         }
         nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
@@ -963,9 +964,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         }
         nout = 1;
     } else {
-        for (int base = 0; base < ncon; base += G::BT) {
+        for (int base = 0, r = 0; base < ncon; base += G::BT, ++r) {
             const int k = base + tid;
-            const int flag = (k < ncon) && cstate[k] == -2;
+            const int flag = (k < ncon) && ((keptbits >> r) & 1u);
             if (!G::any(flag)) continue;
             const int slot = compact_slot(flag, nout, S);
             if (slot >= 0 && slot < MP) {
