@@ -110,9 +110,11 @@ constexpr int OV_RUN = 256;   // vertices per culling box (engine.mesh_table CHU
 __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
 {
     __shared__ unsigned char s_ok[64 * 63 / 2];
+    __shared__ unsigned char s_big[64];    // body's mesh is searched by a whole workgroup (list 0) / a wavefront (list 1)
     const int nb = W.nb, nup = nb * (nb - 1) / 2, np = npairs_of(nb);
     const int sc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!W.active[sc]) return;
+    if (tid < nb) s_big[tid] = W.mesh_nf[W.mesh_id[(size_t)sc * nb + tid]] > WAVE_ITEM_MAX_FACES;
     for (int up = wv; up < nup; up += NT / 64) {
         int i = 0, rem = up;
         while (rem >= nb - 1 - i) { rem -= nb - 1 - i; ++i; }
@@ -167,18 +169,14 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
     if (tid == 0) {
         int cnt[2] = {0, 0};
         for (int up = 0, i = 0, j = 1; up < nup; ++up) {
-            if (s_ok[up]) {
-                ++cnt[W.mesh_nf[W.mesh_id[(size_t)sc * nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1];
-                ++cnt[W.mesh_nf[W.mesh_id[(size_t)sc * nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1];
-            }
+            if (s_ok[up]) { ++cnt[s_big[i] ? 0 : 1]; ++cnt[s_big[j] ? 0 : 1]; }
             if (++j == nb) { ++i; j = i + 1; }
         }
         const int cap = W.B * np;
         int at[2] = {cnt[0] ? atomicAdd(W.n_pairs, cnt[0]) : 0, cnt[1] ? atomicAdd(W.n_pairs + 2, cnt[1]) : 0};
         for (int up = 0, i = 0, j = 1; up < nup; ++up) {
             if (s_ok[up]) {
-                const int li = W.mesh_nf[W.mesh_id[(size_t)sc * nb + i]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
-                const int lj = W.mesh_nf[W.mesh_id[(size_t)sc * nb + j]] > WAVE_ITEM_MAX_FACES ? 0 : 1;
+                const int li = s_big[i] ? 0 : 1, lj = s_big[j] ? 0 : 1;
                 W.pair_list[(size_t)li * cap + at[li]++] = sc * np + i * (nb - 1) + (j - 1);
                 W.pair_list[(size_t)lj * cap + at[lj]++] = sc * np + j * (nb - 1) + i;
             }
