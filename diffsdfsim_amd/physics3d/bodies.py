@@ -49,6 +49,23 @@ class Body3D:
     rot = property(lambda self: self.p[:4])
     pos = property(lambda self: self.p[4:])
 
+    def set_p(self, new_p, update_geom_rotation=True, update_ang_inertia=True):
+        """`Body3D.set_p` (sdf_physics/physics3d/bodies.py:498-511): replace the pose (quaternion wxyz + position).  A
+        world that owns the body picks the new tensor up at its next step."""
+        self.p = get_tensor(new_p)
+
+    @property
+    def M(self):
+        """6x6 generalized mass matrix blockdiag(R I R^T, m 1) at the current pose (bodies.py:431-435, 509-511)."""
+        q = self.p[:4]
+        two_s = 2.0 / (q * q).sum()
+        r, i, j, k = q[0], q[1], q[2], q[3]
+        R = torch.stack([1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                         two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                         two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)]).reshape(3, 3)
+        Iw = R @ self.ang_inertia.to(R) @ R.t()
+        return torch.block_diag(Iw, torch.eye(3, dtype=Iw.dtype, device=Iw.device) * self.mass.to(Iw))
+
     def add_force(self, f):
         self.forces.append(f)
         f.set_body(self)

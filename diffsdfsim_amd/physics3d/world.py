@@ -149,8 +149,17 @@ class World3D(BatchWorld3D):
     t = property(lambda self: self._t)
 
     def _sync_bodies(self):
+        self._views = []
         for i, b in enumerate(self.bodies):
             b.p, b.v = self.pose[0, i], self.vel[0, i]
+            self._views.append((b.p, b.v))
+
+    def _pull_bodies(self):
+        """A body whose pose / velocity tensor was replaced from outside (Body3D.set_p, `body.v = ...`) since the last
+        synchronisation wins over the world's copy, as in the reference where the bodies own the state."""
+        if any(b.p is not vw[0] or b.v is not vw[1] for b, vw in zip(self.bodies, self._views)):
+            self.pose = torch.stack([b.p.to(self.device) for b in self.bodies])[None]
+            self.vel = torch.stack([b.v.to(self.device) for b in self.bodies])[None]
 
     @property
     def contacts(self):
@@ -168,6 +177,7 @@ class World3D(BatchWorld3D):
 
     def step(self, fixed_dt=False):
         self.params = self._ptensors(self._t)      # forces may depend on time (ExternalForce3D.force_func)
+        self._pull_bodies()
         E = self.engine
         self._start = (self._t, self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}, self._n_nodes)
         had = bool(BatchWorld3D.step(self, fixed_dt)[0])

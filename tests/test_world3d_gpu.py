@@ -123,3 +123,19 @@ def test_contact_free_constrained_body_matches_reference():
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) < 1e-10
     assert np.abs(dims.grad.numpy() - g["grad_dims"]).max() < 1e-5 * np.abs(g["grad_dims"]).max()
+
+
+def test_body_set_p_and_mass_matrix():
+    """Body surface of the reference (bodies.py:431-435, 498-511): `M` = blockdiag(R I R^T, m 1); a pose replaced with
+    `body.set_p` is what the world steps from."""
+    g = R.load_rollout("rollout_sphere_notoc")
+    w, floor, ball, rad = build_sphere_world(g, toc=True)
+    M = ball.M.detach()
+    assert torch.allclose(M[3:, 3:], torch.eye(3, dtype=M.dtype, device=M.device) * float(ball.mass))
+    assert torch.allclose(M[:3, :3], ball.ang_inertia.to(M), atol=1e-15)          # identity rotation, isotropic inertia
+    w.step(fixed_dt=True)
+    p = ball.p.detach().clone(); p[5] += 0.25
+    ball.set_p(p)
+    y0 = float(ball.pos[1])
+    w.step(fixed_dt=True)
+    assert abs(float(w.pose[0, 1, 5]) - y0) < 0.05 and float(w.pose[0, 1, 5]) > float(g["traj_p"][1][1][5]) + 0.2
