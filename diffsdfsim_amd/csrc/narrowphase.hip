@@ -31,7 +31,7 @@ using namespace dss;
 constexpr int NT = 256;
 constexpr int MAX_CPT = 8;       // candidates per thread: max_cand <= NT * MAX_CPT
 constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
-constexpr int WAVE_ITEM_MAX_FACES = 16 * 256;   // items that search a bigger mesh take a whole workgroup (WaveGroup::CHCAP runs)
+constexpr int WAVE_ITEM_MAX_FACES = 32 * 256;   // items that search a bigger mesh take a whole workgroup (WaveGroup::CHCAP runs)
 
 __device__ inline int npairs_of(int nb) { return nb * (nb - 1); }
 __device__ inline void pair_of(int dp, int nb, int &a, int &b)
@@ -199,7 +199,7 @@ template <int BT_, int HCAP_, int CHCAP_> struct Group {
     __device__ static inline int any(int x) { if (BT_ == 64) return __ballot(x) != 0ull; else return __syncthreads_or(x); }
 };
 using BlockGroup = Group<256, 1024, 704>;
-using WaveGroup = Group<64, 384, 16>;
+using WaveGroup = Group<64, 384, 32>;
 
 template <class G> struct ScratchT {
     int wave_tot[G::NW];
