@@ -46,7 +46,7 @@ __device__ inline void softplus100(double z, double &h, double &dh)
 // NW waves per workgroup share the activations of NG groups of 4 points; wave w owns neuron tiles [w*8/NW, (w+1)*8/NW)
 template <int NW, int NG> __global__ void __launch_bounds__(64 * NW)
 igr_query_kernel(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
-                 const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad)
+                 const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, int wrt_latent)
 {
     DSS_DYN_LDS(double, X);   // [ROWS][LDX]: row = 4*quantity + point (+16 for the second group of 4 points)
     constexpr int PTS = 4 * NG, ROWS = 4 * PTS, NT = 64 * NW, TPW = 8 / NW;
@@ -64,7 +64,8 @@ igr_query_kernel(const double *pts, const double *latent, const double *W0, cons
         softplus100(z, h, dh);
         const int r0 = 16 * (p / 4) + (p % 4);
         X[r0 * LDX + j] = h;
-        for (int d = 0; d < 3; ++d) X[(r0 + 4 * (d + 1)) * LDX + j] = dh * W0[j * DIN + 2 + d];
+        // tangent seeds: the three point coordinates (inputs 2..4), or the two latent coordinates (inputs 0, 1)
+        for (int d = 0; d < 3; ++d) X[(r0 + 4 * (d + 1)) * LDX + j] = wrt_latent ? (d < 2 ? dh * W0[j * DIN + d] : 0.0) : dh * W0[j * DIN + 2 + d];
     }
     __syncthreads();
 
@@ -78,7 +79,7 @@ igr_query_kernel(const double *pts, const double *latent, const double *W0, cons
                 if (j >= H - DIN) {
                     const int k = j - (H - DIN), quant = (r % 16) / 4, p = 4 * (r / 16) + (r % 4), gp = base + p;
                     if (quant == 0) v = k < 2 ? latent[k] : (gp < n ? pts[3 * gp + k - 2] : 0.0);
-                    else v = (k - 2 == quant - 1) ? 1.0 : 0.0;
+                    else v = ((wrt_latent ? k : k - 2) == quant - 1 && (wrt_latent ? k < 2 : k >= 2)) ? 1.0 : 0.0;
                 }
                 X[r * LDX + j] = v * 0.70710678118654752440;
             }
@@ -139,7 +140,7 @@ igr_query_kernel(const double *pts, const double *latent, const double *W0, cons
 
 template <int NW, int NG>
 void launch(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp, const double *bh,
-            const double *W8, const double *b8, int n, double *sdf, double *grad, hipStream_t stream)
+            const double *W8, const double *b8, int n, double *sdf, double *grad, int wrt_latent, hipStream_t stream)
 {
     constexpr int PTS = 4 * NG;
     const size_t lds = (size_t)4 * PTS * LDX * sizeof(double);
@@ -148,7 +149,7 @@ void launch(const double *pts, const double *latent, const double *W0, const dou
         (void)hipFuncSetAttribute((const void *)igr_query_kernel<NW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
     hipLaunchKernelGGL((igr_query_kernel<NW, NG>), dim3((n + PTS - 1) / PTS), dim3(64 * NW), lds, stream, pts, latent, W0, b0,
-                       Wp, bh, W8, b8, n, sdf, grad);
+                       Wp, bh, W8, b8, n, sdf, grad, wrt_latent);
 }
 
 }  // namespace
@@ -164,8 +165,20 @@ int dss_igr_query(const double *pts, const double *latent, const double *W0, con
     if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
     // big batches (grid builds): 4 waves share 16 points, halving the L2 weight traffic; small ones (contact queries):
     // 2 waves x 8 points so the grid still covers the chip.  Both give bit-identical results.
-    if (n >= 16 * 1024) launch<4, 4>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, (hipStream_t)stream);
-    else launch<2, 2>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, (hipStream_t)stream);
+    if (n >= 16 * 1024) launch<4, 4>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 0, (hipStream_t)stream);
+    else launch<2, 2>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 0, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+// The same network evaluation with the tangents seeded on the latent code instead of the point: grad [n][3] =
+// (d phi / d latent_0, d phi / d latent_1, 0).  This is d phi / d theta of the MeshSDF backward (bodies.py:680-702) for
+// an IGR body; the vertex normals come from dss_igr_query.
+int dss_igr_query_latent_grad(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
+                              const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream)
+{
+    if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
+    if (n >= 16 * 1024) launch<4, 4>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 1, (hipStream_t)stream);
+    else launch<2, 2>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 1, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 

@@ -33,28 +33,81 @@ __global__ void __launch_bounds__(256) sdf_query_kernel(int type, double p0, dou
     if (mask) mask[i] = in ? 1 : 0;
 }
 
-// projection integrals of one face over the (A, B) plane, comp_projection_integrals (bodies.py:260-305)
-struct Proj { double P1, Pa, Paa, Paaa, Pb, Pbb, Pbbb, Pab, Paab, Pabb; };
-__device__ inline void projection_integrals(const double v[3][3], int A, int B, Proj &o)
+// The ten volume-integral contributions of one face (comp_projection_integrals / comp_face_integrals /
+// comp_volume_integrals, bodies.py:260-377): c[0] -> T0, c[1..3] -> 2 T1, c[4..6] -> 3 T2, c[7..9] -> 2 TP.
+// Templated on the scalar so that the backward differentiates the same code with dual numbers.
+template <class T> __device__ inline T pick3(int ax, int A, int B, const T &a, const T &b, const T &c) { return ax == A ? a : (ax == B ? b : c); }
+template <class T> __device__ inline void face_integrals(const T v[3][3], T *c)
 {
-    double P1 = 0, Pa = 0, Paa = 0, Paaa = 0, Pb = 0, Pbb = 0, Pbbb = 0, Pab = 0, Paab = 0, Pabb = 0;
+    T nrm[3];
+    const T e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+    const T e2[3] = {v[2][0] - v[1][0], v[2][1] - v[1][1], v[2][2] - v[1][2]};
+    cross(e1, e2, nrm);
+    const T ln = t_sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    for (int i = 0; i < 3; ++i) nrm[i] = nrm[i] / ln;
+    const T w = -(nrm[0] * v[0][0] + nrm[1] * v[0][1] + nrm[2] * v[0][2]);
+    int C = 0;   // torch.argmax: first index of the maximum
+    for (int i = 1; i < 3; ++i) if (fabs(val(nrm[i])) > fabs(val(nrm[C]))) C = i;
+    const int A = (C + 1) % 3, B = (A + 1) % 3;
+    T P1(0.0), Pa(0.0), Paa(0.0), Paaa(0.0), Pb(0.0), Pbb(0.0), Pbbb(0.0), Pab(0.0), Paab(0.0), Pabb(0.0);
     for (int e = 0; e < 3; ++e) {
-        const double a0 = v[e][A], b0 = v[e][B], a1 = v[(e + 1) % 3][A], b1 = v[(e + 1) % 3][B];
-        const double da = a1 - a0, db = b1 - b0;
-        const double a0_2 = a0 * a0, a0_3 = a0_2 * a0, a0_4 = a0_3 * a0, b0_2 = b0 * b0, b0_3 = b0_2 * b0, b0_4 = b0_3 * b0;
-        const double a1_2 = a1 * a1, a1_3 = a1_2 * a1, b1_2 = b1 * b1, b1_3 = b1_2 * b1;
-        const double C1 = a1 + a0, Ca = a1 * C1 + a0_2, Caa = a1 * Ca + a0_3, Caaa = a1 * Caa + a0_4;
-        const double Cb = b1 * (b1 + b0) + b0_2, Cbb = b1 * Cb + b0_3, Cbbb = b1 * Cbb + b0_4;
-        const double Cab = 3 * a1_2 + 2 * a1 * a0 + a0_2, Kab = a1_2 + 2 * a1 * a0 + 3 * a0_2;
-        const double Caab = a0 * Cab + 4 * a1_3, Kaab = a1 * Kab + 4 * a0_3;
-        const double Cabb = 4 * b1_3 + 3 * b1_2 * b0 + 2 * b1 * b0_2 + b0_3, Kabb = b1_3 + 2 * b1_2 * b0 + 3 * b1 * b0_2 + 4 * b0_3;
-        P1 += db * C1; Pa += db * Ca; Paa += db * Caa; Paaa += db * Caaa;
-        Pb += da * Cb; Pbb += da * Cbb; Pbbb += da * Cbbb;
-        Pab += db * (b1 * Cab + b0 * Kab); Paab += db * (b1 * Caab + b0 * Kaab); Pabb += da * (a1 * Cabb + a0 * Kabb);
+        const T a0 = pick3(A, 0, 1, v[e][0], v[e][1], v[e][2]), b0 = pick3(B, 0, 1, v[e][0], v[e][1], v[e][2]);
+        const T a1 = pick3(A, 0, 1, v[(e + 1) % 3][0], v[(e + 1) % 3][1], v[(e + 1) % 3][2]);
+        const T b1 = pick3(B, 0, 1, v[(e + 1) % 3][0], v[(e + 1) % 3][1], v[(e + 1) % 3][2]);
+        const T da = a1 - a0, db = b1 - b0;
+        const T a0_2 = a0 * a0, a0_3 = a0_2 * a0, a0_4 = a0_3 * a0, b0_2 = b0 * b0, b0_3 = b0_2 * b0, b0_4 = b0_3 * b0;
+        const T a1_2 = a1 * a1, a1_3 = a1_2 * a1, b1_2 = b1 * b1, b1_3 = b1_2 * b1;
+        const T C1 = a1 + a0, Ca = a1 * C1 + a0_2, Caa = a1 * Ca + a0_3, Caaa = a1 * Caa + a0_4;
+        const T Cb = b1 * (b1 + b0) + b0_2, Cbb = b1 * Cb + b0_3, Cbbb = b1 * Cbb + b0_4;
+        const T Cab = 3.0 * a1_2 + 2.0 * a1 * a0 + a0_2, Kab = a1_2 + 2.0 * a1 * a0 + 3.0 * a0_2;
+        const T Caab = a0 * Cab + 4.0 * a1_3, Kaab = a1 * Kab + 4.0 * a0_3;
+        const T Cabb = 4.0 * b1_3 + 3.0 * b1_2 * b0 + 2.0 * b1 * b0_2 + b0_3, Kabb = b1_3 + 2.0 * b1_2 * b0 + 3.0 * b1 * b0_2 + 4.0 * b0_3;
+        P1 = P1 + db * C1; Pa = Pa + db * Ca; Paa = Paa + db * Caa; Paaa = Paaa + db * Caaa;
+        Pb = Pb + da * Cb; Pbb = Pbb + da * Cbb; Pbbb = Pbbb + da * Cbbb;
+        Pab = Pab + db * (b1 * Cab + b0 * Kab); Paab = Paab + db * (b1 * Caab + b0 * Kaab); Pabb = Pabb + da * (a1 * Cabb + a0 * Kabb);
     }
-    o.P1 = P1 / 2.0; o.Pa = Pa / 6.0; o.Paa = Paa / 12.0; o.Paaa = Paaa / 20.0;
-    o.Pb = Pb / -6.0; o.Pbb = Pbb / -12.0; o.Pbbb = Pbbb / -20.0;
-    o.Pab = Pab / 24.0; o.Paab = Paab / 60.0; o.Pabb = Pabb / -60.0;
+    P1 = P1 / 2.0; Pa = Pa / 6.0; Paa = Paa / 12.0; Paaa = Paaa / 20.0;
+    Pb = Pb / -6.0; Pbb = Pbb / -12.0; Pbbb = Pbbb / -20.0;
+    Pab = Pab / 24.0; Paab = Paab / 60.0; Pabb = Pabb / -60.0;
+    // comp_face_integrals (bodies.py:308-345)
+    const T nC = pick3(C, 0, 1, nrm[0], nrm[1], nrm[2]), nA = pick3(A, 0, 1, nrm[0], nrm[1], nrm[2]), nB = pick3(B, 0, 1, nrm[0], nrm[1], nrm[2]);
+    const T k1 = 1.0 / nC, k2 = k1 * k1, k3 = k2 * k1, k4 = k3 * k1;
+    const T Fa = k1 * Pa, Fb = k1 * Pb, Fc = -k2 * (nA * Pa + nB * Pb + w * P1);
+    const T Faa = k1 * Paa, Fbb = k1 * Pbb;
+    const T Fcc = k3 * (nA * nA * Paa + 2.0 * nA * nB * Pab + nB * nB * Pbb + w * (2.0 * (nA * Pa + nB * Pb) + w * P1));
+    const T Faaa = k1 * Paaa, Fbbb = k1 * Pbbb;
+    const T Fccc = -k4 * (nA * nA * nA * Paaa + 3.0 * nA * nA * nB * Paab + 3.0 * nA * nB * nB * Pabb + nB * nB * nB * Pbbb
+                          + 3.0 * w * (nA * nA * Paa + 2.0 * nA * nB * Pab + nB * nB * Pbb)
+                          + w * w * (3.0 * (nA * Pa + nB * Pb) + w * P1));
+    const T Faab = k1 * Paab, Fbbc = -k2 * (nA * Pabb + nB * Pbbb + w * Pbb);
+    const T Fcca = k3 * (nA * nA * Paaa + 2.0 * nA * nB * Paab + nB * nB * Pabb + w * (2.0 * (nA * Paa + nB * Pab) + w * Pa));
+    // comp_volume_integrals (bodies.py:348-377): the x-coordinate term of T0, per-axis scatter of the others
+    c[0] = nrm[0] * pick3(0, A, B, Fa, Fb, Fc);
+    for (int ax = 0; ax < 3; ++ax) {
+        c[1 + ax] = pick3(ax, A, B, nA * Faa, nB * Fbb, nC * Fcc);
+        c[4 + ax] = pick3(ax, A, B, nA * Faaa, nB * Fbbb, nC * Fccc);
+        c[7 + ax] = pick3(ax, A, B, nA * Faab, nB * Fbbc, nC * Fcca);
+    }
+}
+
+// workgroup-wide ordered sums of the ten integrals over the faces of one mesh (fixed tree: reproducible)
+__device__ inline void mesh_totals(const double *V, const int *F, int nf, double *red, double *tot)
+{
+    const int tid = threadIdx.x;
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = tid; f < nf; f += 256) {
+        double v[3][3], c[10];
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) v[k][i] = V[(size_t)F[3 * f + k] * 3 + i];
+        face_integrals(v, c);
+        for (int q = 0; q < 10; ++q) acc[q] += c[q];
+    }
+    for (int q = 0; q < 10; ++q) {
+        red[tid] = acc[q];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+        tot[q] = red[0];
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(256) mesh_inertia_kernel(const double *verts, const int *faces, const int *voff,
@@ -65,46 +118,8 @@ __global__ void __launch_bounds__(256) mesh_inertia_kernel(const double *verts, 
     const int m = blockIdx.x, tid = threadIdx.x, nf = nfs[m];
     const double *V = verts + (size_t)voff[m] * 3;
     const int *F = faces + (size_t)foff[m] * 3;
-    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // T0, T1[3], T2[3], TP[3] before the final /2, /3, /2
-    for (int f = tid; f < nf; f += 256) {
-        double v[3][3], nrm[3];
-        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) v[k][i] = V[(size_t)F[3 * f + k] * 3 + i];
-        const double e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
-        const double e2[3] = {v[2][0] - v[1][0], v[2][1] - v[1][1], v[2][2] - v[1][2]};
-        cross(e1, e2, nrm);
-        const double ln = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        for (int i = 0; i < 3; ++i) nrm[i] /= ln;
-        const double w = -(nrm[0] * v[0][0] + nrm[1] * v[0][1] + nrm[2] * v[0][2]);
-        int C = 0;   // torch.argmax: first index of the maximum
-        for (int i = 1; i < 3; ++i) if (fabs(nrm[i]) > fabs(nrm[C])) C = i;
-        const int A = (C + 1) % 3, B = (A + 1) % 3;
-        Proj P;
-        projection_integrals(v, A, B, P);
-        // comp_face_integrals (bodies.py:308-345)
-        const double k1 = 1.0 / nrm[C], k2 = k1 * k1, k3 = k2 * k1, k4 = k3 * k1, nA = nrm[A], nB = nrm[B];
-        const double Fa = k1 * P.Pa, Fb = k1 * P.Pb, Fc = -k2 * (nA * P.Pa + nB * P.Pb + w * P.P1);
-        const double Faa = k1 * P.Paa, Fbb = k1 * P.Pbb;
-        const double Fcc = k3 * (nA * nA * P.Paa + 2 * nA * nB * P.Pab + nB * nB * P.Pbb + w * (2 * (nA * P.Pa + nB * P.Pb) + w * P.P1));
-        const double Faaa = k1 * P.Paaa, Fbbb = k1 * P.Pbbb;
-        const double Fccc = -k4 * (nA * nA * nA * P.Paaa + 3 * nA * nA * nB * P.Paab + 3 * nA * nB * nB * P.Pabb + nB * nB * nB * P.Pbbb
-                                   + 3 * w * (nA * nA * P.Paa + 2 * nA * nB * P.Pab + nB * nB * P.Pbb)
-                                   + w * w * (3 * (nA * P.Pa + nB * P.Pb) + w * P.P1));
-        const double Faab = k1 * P.Paab, Fbbc = -k2 * (nA * P.Pabb + nB * P.Pbbb + w * P.Pbb);
-        const double Fcca = k3 * (nA * nA * P.Paaa + 2 * nA * nB * P.Paab + nB * nB * P.Pabb + w * (2 * (nA * P.Paa + nB * P.Pab) + w * P.Pa));
-        // comp_volume_integrals (bodies.py:348-377): the x-coordinate term of T0, per-axis scatter of the others
-        acc[0] += nrm[0] * (A == 0 ? Fa : (B == 0 ? Fb : Fc));
-        acc[1 + A] += nA * Faa;  acc[1 + B] += nB * Fbb;  acc[1 + C] += nrm[C] * Fcc;
-        acc[4 + A] += nA * Faaa; acc[4 + B] += nB * Fbbb; acc[4 + C] += nrm[C] * Fccc;
-        acc[7 + A] += nA * Faab; acc[7 + B] += nB * Fbbc; acc[7 + C] += nrm[C] * Fcca;
-    }
     double tot[10];
-    for (int q = 0; q < 10; ++q) {
-        red[tid] = acc[q];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        tot[q] = red[0];
-        __syncthreads();
-    }
+    mesh_totals(V, F, nf, red, tot);
     if (tid == 0) {
         const double T0 = tot[0];
         const double T2[3] = {tot[4] / 3.0, tot[5] / 3.0, tot[6] / 3.0}, TP[3] = {tot[7] / 2.0, tot[8] / 2.0, tot[9] / 2.0};
@@ -115,6 +130,44 @@ __global__ void __launch_bounds__(256) mesh_inertia_kernel(const double *verts, 
         o[5] = o[7] = -density * TP[1];
         o[6] = o[2] = -density * TP[2];
         if (vol) vol[m] = T0;
+    }
+}
+
+// d (sum_ab gJ_ab J_ab) / d verts.  J = rho (sums of T2) / -rho TP with rho = mass / T0 (bodies.py:380-395): the adjoint
+// of the ten totals is a handful of scalars; every face then differentiates its own contribution with dual numbers
+// (three passes, one per vertex) and adds it to its vertices.  Atomic adds: the summation order over the faces that
+// share a vertex is not fixed (world-construction gradient, last-bit differences between runs).
+__global__ void __launch_bounds__(256) mesh_inertia_bwd_kernel(const double *verts, const int *faces, int nf, double mass,
+                                                              const double *gJ, double *gverts)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double tot[10];
+    mesh_totals(verts, faces, nf, red, tot);
+    const double T0 = tot[0], rho = mass / T0;
+    const double T2[3] = {tot[4] / 3.0, tot[5] / 3.0, tot[6] / 3.0}, TP[3] = {tot[7] / 2.0, tot[8] / 2.0, tot[9] / 2.0};
+    const double Jv[9] = {rho * (T2[1] + T2[2]), -rho * TP[0], -rho * TP[2], -rho * TP[0], rho * (T2[2] + T2[0]), -rho * TP[1],
+                          -rho * TP[2], -rho * TP[1], rho * (T2[0] + T2[1])};
+    double L = 0.0;
+    for (int e = 0; e < 9; ++e) L += gJ[e] * Jv[e];
+    double gT[10];
+    gT[0] = -L / T0;
+    gT[1] = gT[2] = gT[3] = 0.0;
+    gT[4] = rho / 3.0 * (gJ[4] + gJ[8]); gT[5] = rho / 3.0 * (gJ[0] + gJ[8]); gT[6] = rho / 3.0 * (gJ[0] + gJ[4]);
+    gT[7] = -rho / 2.0 * (gJ[1] + gJ[3]); gT[8] = -rho / 2.0 * (gJ[5] + gJ[7]); gT[9] = -rho / 2.0 * (gJ[2] + gJ[6]);
+    typedef Dual<3> D;
+    for (int f = tid; f < nf; f += 256) {
+        for (int vs = 0; vs < 3; ++vs) {
+            D v[3][3], c[10];
+            for (int k = 0; k < 3; ++k)
+                for (int i = 0; i < 3; ++i) { v[k][i] = D(verts[(size_t)faces[3 * f + k] * 3 + i]); if (k == vs) v[k][i].d[i] = 1.0; }
+            face_integrals(v, c);
+            for (int i = 0; i < 3; ++i) {
+                double g = 0.0;
+                for (int q = 0; q < 10; ++q) g += gT[q] * c[q].d[i];
+                atomicAdd(&gverts[(size_t)faces[3 * f + vs] * 3 + i], g);
+            }
+        }
     }
 }
 
@@ -150,6 +203,15 @@ int dss_selftest_sqrt(const double *x, int n, int *mismatches, void *stream)
 {
     if (!x || !mismatches || n <= 0) return DSS_E_BADARG;
     hipLaunchKernelGGL(sqrt_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n, mismatches);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+int dss_mesh_inertia_backward(const double *verts, const int *faces, int nv, int nf, double mass, const double *grad_J,
+                              double *grad_verts, void *stream)
+{
+    if (!verts || !faces || !grad_J || !grad_verts || nv <= 0 || nf <= 0) return DSS_E_BADARG;
+    (void)hipMemsetAsync(grad_verts, 0, (size_t)nv * 3 * sizeof(double), (hipStream_t)stream);
+    hipLaunchKernelGGL(mesh_inertia_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, verts, faces, nf, mass, grad_J, grad_verts);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 

@@ -33,14 +33,16 @@ def pack_weights(Ws, bs, device="cuda"):
     return dict(W0=t(Ws[0]), b0=t(bs[0]), Wp=t(packed), bh=t(bh), W8=t(Ws[8][0]), b8=t(bs[8]))
 
 
-def igr_query(pts, latent, P):
-    """pts [n,3], latent [2] (float64, HIP device) -> sdf [n], d sdf / d xyz [n,3]."""
+def igr_query(pts, latent, P, wrt="xyz"):
+    """pts [n,3], latent [2] (float64, HIP device) -> sdf [n], d sdf / d xyz [n,3]
+    (wrt="latent": [n,3] = d sdf / d latent_0, d sdf / d latent_1, 0)."""
     _lib.require_device(pts, latent)
     L = _lib.lib()
     n = pts.shape[0]
     sdf = torch.empty(n, dtype=torch.float64, device=pts.device)
     grad = torch.empty(n, 3, dtype=torch.float64, device=pts.device)
-    rc = L.dss_igr_query(_lib.ptr(pts.contiguous()), _lib.ptr(latent.contiguous()), _lib.ptr(P["W0"]), _lib.ptr(P["b0"]),
+    fn = L.dss_igr_query_latent_grad if wrt == "latent" else L.dss_igr_query
+    rc = fn(_lib.ptr(pts.contiguous()), _lib.ptr(latent.contiguous()), _lib.ptr(P["W0"]), _lib.ptr(P["b0"]),
                          _lib.ptr(P["Wp"]), _lib.ptr(P["bh"]), _lib.ptr(P["W8"]), _lib.ptr(P["b8"]), int(n), _lib.ptr(sdf),
                          _lib.ptr(grad), _lib.stream_ptr(pts.device))
     _lib.check(rc, "dss_igr_query")

@@ -63,3 +63,33 @@ def mesh_inertia(verts, faces, mass, return_volume=False):
     if single:
         return (J[0], vol[0]) if return_volume else J[0]
     return (J, vol) if return_volume else J
+
+
+class _MeshInertiaFn(torch.autograd.Function):
+    """J(verts, mass) of one closed triangle mesh, differentiable like the reference's get_ang_inertia
+    (`bodies.py:380-395`, autograd there): backward = dss_mesh_inertia_backward."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, mass):
+        V = _dev(verts.detach())
+        F = _dev(faces, torch.int32)
+        J = mesh_inertia(V, F, float(mass))
+        ctx.save_for_backward(V, F, J)
+        ctx.mass, ctx.vdev, ctx.mdev = float(mass), verts.device, mass.device if torch.is_tensor(mass) else None
+        return J.to(verts.device)
+
+    @staticmethod
+    def backward(ctx, gJ):
+        V, F, J = ctx.saved_tensors
+        g = _dev(gJ).reshape(9)
+        gv = torch.empty_like(V)
+        rc = _lib.lib().dss_mesh_inertia_backward(_lib.ptr(V), _lib.ptr(F), int(V.shape[0]), int(F.shape[0]),
+                                                  _lib.ctypes.c_double(ctx.mass), _lib.ptr(g), _lib.ptr(gv), _lib.stream_ptr(V.device))
+        _lib.check(rc, "dss_mesh_inertia_backward")
+        gm = None if ctx.mdev is None else ((g.reshape(3, 3) * J).sum() / ctx.mass).to(ctx.mdev)     # J is linear in the mass
+        return gv.to(ctx.vdev), None, gm
+
+
+def mesh_inertia_diff(verts, faces, mass):
+    """Differentiable (w.r.t. verts and mass) inertia tensor of one closed mesh; verts a torch tensor [V,3]."""
+    return _MeshInertiaFn.apply(verts, faces, mass if torch.is_tensor(mass) else torch.tensor(float(mass), dtype=torch.float64))

@@ -89,10 +89,35 @@ def primitive_mesh(shape_type, prm_unit, res=128):
     return _PrimitiveMeshSDF.apply(torch.as_tensor(prm_unit, dtype=torch.float64), int(shape_type), int(res))
 
 
+class _IgrMeshSDF(torch.autograd.Function):
+    """MeshSDF for the IGR network: forward = res^3 evaluations on the fp64 matrix cores + marching cubes; backward =
+    dL/dlatent = sum_v -(dL/dv . n_v) d phi / d latent (v)  (bodies.py:680-702), normals and latent derivatives from
+    two more network evaluations at the vertices (dss_igr_query, dss_igr_query_latent_grad)."""
+
+    @staticmethod
+    def forward(ctx, latent, packed_weights, res):
+        from .igr import igr_query
+        dev = packed_weights["W0"].device
+        lat = _dev(latent.detach())
+        sdf, _ = igr_query(_grid(res, dev), lat, packed_weights)
+        verts, faces = marching_cubes(sdf.reshape(res, res, res), 0.0)
+        verts = verts / (res - 1) * 2.0 - 1.0
+        ctx.save_for_backward(verts, lat)
+        ctx.P, ctx.ldev = packed_weights, latent.device
+        ctx.mark_non_differentiable(faces)
+        return verts, faces
+
+    @staticmethod
+    def backward(ctx, grad_v, _grad_f):
+        from .igr import igr_query
+        verts, lat = ctx.saved_tensors
+        _, gx = igr_query(verts, lat, ctx.P)                    # d phi / d xyz at the vertices
+        _, gl = igr_query(verts, lat, ctx.P, wrt="latent")      # d phi / d latent at the vertices
+        nrm = gx / gx.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        dl_ds = -(grad_v * nrm).sum(1)
+        return (dl_ds[:, None] * gl[:, :2]).sum(0).to(ctx.ldev), None, None
+
+
 def igr_mesh(latent, packed_weights, res=128):
-    """Mesh of the IGR level set in [-1,1]^3 (forward only): res^3 evaluations on the fp64 matrix cores."""
-    from .igr import igr_query
-    dev = packed_weights["W0"].device
-    sdf, _ = igr_query(_grid(res, dev), _dev(latent), packed_weights)
-    verts, faces = marching_cubes(sdf.reshape(res, res, res), 0.0)
-    return verts / (res - 1) * 2.0 - 1.0, faces
+    """Mesh of the IGR level set in [-1,1]^3, differentiable w.r.t. the latent code (MeshSDF)."""
+    return _IgrMeshSDF.apply(torch.as_tensor(latent, dtype=torch.float64), packed_weights, int(res))

@@ -251,6 +251,9 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream);
 size_t dss_igr_packed_doubles(void);
 int dss_igr_query(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
                   const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream);
+/* Same evaluation, tangents on the latent code: grad [n][3] = (d sdf / d latent_0, d sdf / d latent_1, 0). */
+int dss_igr_query_latent_grad(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
+                              const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * World-construction side of the path
@@ -267,6 +270,11 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
                   unsigned char *overlap_mask, void *stream);
 int dss_mesh_inertia(const double *verts, const int *faces, const int *mesh_voff, const int *mesh_foff, const int *mesh_nf,
                      int nmesh, const double *mass, double *J, double *volume, void *stream);
+
+/* Adjoint of dss_mesh_inertia for ONE mesh: grad_verts [nv][3] = d (sum_ab grad_J[a][b] J[a][b]) / d verts
+ * (the reference differentiates get_ang_inertia with autograd, bodies.py:380-395). */
+int dss_mesh_inertia_backward(const double *verts, const int *faces, int nv, int nf, double mass, const double *grad_J,
+                              double *grad_verts, void *stream);
 
 /* Self-test of the shared-reciprocal triple division the geometry kernels use (csrc/geom.h: div3): counts the
  * quotients num[i][k] / den[i] whose bit pattern differs from an IEEE division on the device. */

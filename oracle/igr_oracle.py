@@ -35,13 +35,18 @@ def softplus100(z):
     return h, dh
 
 
-def query(pts, latent, Ws, bs):
-    """-> sdf [n], grad [n,3] = d sdf / d xyz (what autograd returns in SDF3D.query_sdfs, bodies.py:730-745)."""
+def query(pts, latent, Ws, bs, wrt="xyz"):
+    """-> sdf [n], grad [n,3] = d sdf / d xyz (what autograd returns in SDF3D.query_sdfs, bodies.py:730-745), or with
+    wrt="latent" (d sdf / d latent_0, d sdf / d latent_1, 0): the d phi / d theta of the MeshSDF backward."""
     pts = np.asarray(pts, np.float64)
     n = len(pts)
     inp = np.concatenate([np.broadcast_to(latent, (n, 2)), pts], 1)
     x = inp
-    J = np.zeros((n, DIN, 3)); J[:, 2:, :] = np.eye(3)      # d input / d xyz
+    J = np.zeros((n, DIN, 3))
+    if wrt == "latent":
+        J[:, 0, 0] = 1.0; J[:, 1, 1] = 1.0                  # d input / d latent
+    else:
+        J[:, 2:, :] = np.eye(3)                             # d input / d xyz
     Jx = J
     for l in range(9):
         if l == SKIP:

@@ -117,7 +117,7 @@ class EmuBackend:
         return int(t.reshape(-1)[0])
 
 
-def igr_query(pts, latent, Ws, bs):
+def igr_query(pts, latent, Ws, bs, wrt="xyz"):
     L = lib()
     H = 128
     packed = np.zeros((7, 8, 32, 64)); bh = np.zeros((7, H)); lane = np.arange(64)
@@ -129,7 +129,8 @@ def igr_query(pts, latent, Ws, bs):
     pts = _c(pts); n = len(pts)
     sdf = np.zeros(n); grad = np.zeros((n, 3))
     W0, b0, W8, b8, lat = _c(Ws[0]), _c(bs[0]), _c(Ws[8][0]), _c(bs[8]), _c(latent)
-    rc = L.dss_igr_query(_p(pts), _p(lat), _p(W0), _p(b0), _p(packed), _p(bh), _p(W8), _p(b8), n, _p(sdf), _p(grad), None)
+    fn = L.dss_igr_query_latent_grad if wrt == "latent" else L.dss_igr_query
+    rc = fn(_p(pts), _p(lat), _p(W0), _p(b0), _p(packed), _p(bh), _p(W8), _p(b8), n, _p(sdf), _p(grad), None)
     assert rc == 0
     return sdf, grad
 
@@ -178,5 +179,13 @@ def meshsdf_backward(shape_type, unit_prm, unit_verts, gbar):
     prm = _c(np.concatenate([np.asarray(unit_prm, np.float64).reshape(-1), np.zeros(3)])[:3])
     V = _c(unit_verts); Gb = _c(gbar); out = np.zeros(3)
     rc = L.dss_meshsdf_backward(int(shape_type), _p(prm), _p(V), _p(Gb), len(V), _p(out), None)
+    assert rc == 0
+    return out
+
+
+def mesh_inertia_backward(verts, faces, mass, gJ):
+    L = lib()
+    V = _c(verts); F = _c(faces, np.int32); g = _c(gJ).reshape(9); out = np.zeros_like(V)
+    rc = L.dss_mesh_inertia_backward(_p(V), _p(F), len(V), len(F), ctypes.c_double(mass), _p(g), _p(out), None)
     assert rc == 0
     return out

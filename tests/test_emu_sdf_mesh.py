@@ -27,3 +27,19 @@ def test_mesh_inertia_matches_reference(name):
     J, vol = emu.mesh_inertia(g[name + "_verts"], g[name + "_faces"], float(g[name + "_mass"]))
     assert np.abs(J - g[name + "_J"]).max() < 1e-11 * np.abs(g[name + "_J"]).max()
     assert vol > 0
+
+
+def test_mesh_inertia_backward_matches_finite_differences():
+    """Adjoint of get_ang_inertia w.r.t. the vertices (the reference uses autograd, bodies.py:380-395)."""
+    from diffsdfsim_amd import meshes
+    v, f = meshes.icosphere(1)
+    v = v * np.array([0.7, 0.5, 0.9]) + np.array([0.05, -0.02, 0.03])
+    r = np.random.default_rng(2)
+    gJ = r.standard_normal((3, 3))
+    g = emu.mesh_inertia_backward(v, f, 1.7, gJ)
+    h = 1e-6
+    for (i, d) in [(0, 0), (5, 1), (11, 2), (20, 0)]:
+        vp, vm = v.copy(), v.copy()
+        vp[i, d] += h; vm[i, d] -= h
+        fd = ((emu.mesh_inertia(vp, f, 1.7)[0] - emu.mesh_inertia(vm, f, 1.7)[0]) * gJ).sum() / (2 * h)
+        assert abs(g[i, d] - fd) < 1e-6 * max(1.0, abs(fd)), (i, d, g[i, d], fd)
