@@ -25,14 +25,22 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm):
         E = world.engine
-        for name, t in zip(("pose", "vel") + PARAMS, (pose, vel, mass, inertia.reshape(E.B, E.nb, 9), rest, fric, fext, prm)):
-            E.arr[name].copy_(t.detach())
+        # upload only what changed since the last step: parameters are usually the same tensors all along, and the
+        # state handed in is usually the very tensor the previous step handed out (the engine still holds its values)
+        seen = world.__dict__.setdefault("_uploaded", {})
+        for name, t in zip(("pose", "vel") + PARAMS, (pose, vel, mass, inertia, rest, fric, fext, prm)):
+            hit = seen.get(name)      # (tensor, version): the reference keeps the tensor alive, so `is` cannot be fooled by id reuse
+            if hit is not None and hit[0] is t and hit[1] == t._version:
+                continue
+            E.arr[name].copy_(t.detach().reshape(E.arr[name].shape))
+            seen[name] = (t, t._version)
         nsub0 = E.arr["nsub"].clone()
         att = E.step() if fixed_dt else E.step_once()
         ctx.world, ctx.nsub0, ctx.att = world, nsub0, att
         ctx.index = world._n_nodes
         world._n_nodes += 1
-        return E.arr["pose"].clone(), E.arr["vel"].clone()
+        out_pose, out_vel = E.arr["pose"].clone(), E.arr["vel"].clone()
+        return out_pose, out_vel
 
     @staticmethod
     def backward(ctx, g_pose, g_vel):
@@ -86,9 +94,21 @@ class BatchWorld3D:
 
     def step(self, fixed_dt=True):
         P = self.params
-        to = lambda x: x.to(self.device)
-        self.pose, self.vel = _StepFn.apply(self, fixed_dt, to(self.pose), to(self.vel), to(P["mass"]), to(P["inertia"]),
-                                            to(P["restitution"]), to(P["fric"]), to(P["fext"]), to(P["shape_prm"]))
+        dev_cache = self.__dict__.setdefault("_dev_params", {})
+
+        def to(name, x):      # device copy of a parameter, made once per (tensor, version)
+            if x.device == self.device:
+                return x
+            hit = dev_cache.get(name)
+            if hit is None or hit[0] is not x or hit[1] != x._version:
+                hit = (x, x._version, x.to(self.device))
+                dev_cache[name] = hit
+            return hit[2]
+        self.pose, self.vel = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
+                                            to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
+                                            to("fext", P["fext"]), to("shape_prm", P["shape_prm"]))
+        up = self.__dict__.setdefault("_uploaded", {})
+        up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
         return self.engine.get("nc") > 0
 
     def contact_pairs(self, s=0):
