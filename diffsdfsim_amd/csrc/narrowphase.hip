@@ -107,7 +107,8 @@ __device__ inline bool box_hits(const Region &r, const double *bx)
 // chain of dependent loads).  The surviving pairs of the scene are appended to the work lists with ONE atomic per
 // list and scene: a per-pair atomicAdd on two global counters serialises tens of thousands of wavefronts.
 constexpr int OV_RUN = 256;   // vertices per culling box (engine.mesh_table CHUNK)
-__global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
+constexpr int OV_NT = 256;    // eight wavefronts per scene: 28 pairs of an 8-body scene in four rounds
+__global__ void __launch_bounds__(OV_NT) overlap_kernel(DssWorld W)
 {
     __shared__ unsigned char s_ok[64 * 63 / 2];
     __shared__ unsigned char s_big[64];    // body's mesh is searched by a whole workgroup (list 0) / a wavefront (list 1)
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
     const int sc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!W.active[sc]) return;
     if (tid < nb) s_big[tid] = W.mesh_nf[W.mesh_id[(size_t)sc * nb + tid]] > WAVE_ITEM_MAX_FACES;
-    for (int up = wv; up < nup; up += NT / 64) {
+    for (int up = wv; up < nup; up += OV_NT / 64) {
         int i = 0, rem = up;
         while (rem >= nb - 1 - i) { rem -= nb - 1 - i; ++i; }
         const int j = i + 1 + rem;
@@ -173,7 +174,10 @@ __global__ void __launch_bounds__(NT) overlap_kernel(DssWorld W)
             if (++j == nb) { ++i; j = i + 1; }
         }
         const int cap = W.B * np;
-        int at[2] = {cnt[0] ? atomicAdd(W.n_pairs, cnt[0]) : 0, cnt[1] ? atomicAdd(W.n_pairs + 2, cnt[1]) : 0};
+        // both list lengths live in one 64-bit word (n_pairs[0], n_pairs[1]): one atomic per scene reserves both ranges
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(W.n_pairs),
+                                                 (unsigned long long)(unsigned)cnt[0] | ((unsigned long long)(unsigned)cnt[1] << 32));
+        int at[2] = {(int)(old & 0xffffffffull), (int)(old >> 32)};
         for (int up = 0, i = 0, j = 1; up < nup; ++up) {
             if (s_ok[up]) {
                 const int li = s_big[i] ? 0 : 1, lj = s_big[j] ? 0 : 1;
@@ -986,8 +990,8 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 }
 
 // persistent: groups pull items off the active-pair lists through shared cursors so that the long items (a 176 k-face
-// floor against a box) do not leave a static-partition tail.  n_pairs = {count, cursor} x {block list, wave list,
-// deferred list}; pair_list = three segments of B*npairs.  Every workgroup first helps with the block list (all four
+// floor against a box) do not leave a static-partition tail.  n_pairs = {block-list length, wave-list length, block
+// cursor, wave cursor, deferred-list length, deferred cursor}; pair_list = three segments of B*npairs.  Every workgroup first helps with the block list (all four
 // wavefronts on one item), then its wavefronts split up and walk the wave list independently.  A wave item that
 // outgrows the wave-sized scratch is appended to the deferred list, which a second launch works off block-wise.
 #ifndef DSS_NP_WAVES
@@ -1003,11 +1007,11 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
     __shared__ int s_item;
     const int cap = W.B * npairs_of(W.nb), seg = DEFERRED ? 2 : 0;
     {
-        const int n = W.n_pairs[2 * seg];
+        const int n = W.n_pairs[DEFERRED ? 4 : 0];
         const int *list = W.pair_list + (size_t)seg * cap;
         for (;;) {
             __syncthreads();
-            if (threadIdx.x == 0) s_item = atomicAdd(W.n_pairs + 2 * seg + 1, 1);
+            if (threadIdx.x == 0) s_item = atomicAdd(W.n_pairs + (DEFERRED ? 5 : 2), 1);
             __syncthreads();
             const int it = s_item;
             if (it >= n) break;
@@ -1016,7 +1020,7 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
     }
     if (DEFERRED) return;
     __syncthreads();   // nobody still reads the block scratch
-    const int n = W.n_pairs[2], lane = threadIdx.x & 63;
+    const int n = W.n_pairs[1], lane = threadIdx.x & 63;
     const int *list = W.pair_list + cap;
     ScratchT<WaveGroup> &Sw = S.wav[threadIdx.x >> 6];
     for (;;) {
@@ -1104,8 +1108,8 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
         return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
     }
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
-    (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // {count, cursor} x {block, wave, deferred}
-    hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(NT), 0, stream, W);
+    (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // counts and cursors of the three lists
+    hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(OV_NT), 0, stream, W);
     // 256 CUs x DSS_NP_WAVES resident workgroups walk the work lists; no idle dispatches
     const int grid = np_grid(W.B, W.nb);
     hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);

@@ -164,7 +164,8 @@ typedef struct DssWorld {
     int *ovl;                /* [B][nb][nb] overlap flags */
     int *pair_list;          /* [3][B*npairs] active (scene*npairs + directed pair) work items of this attempt:
                                 workgroup items, wavefront items, wavefront items deferred to a workgroup */
-    int *n_pairs;            /* [3][2]: list length, work cursor of each list */
+    int *n_pairs;            /* [6]: workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
+                                work cursors, deferred-list length and cursor */
     int *invalid;            /* [B] penetration > tol found in this attempt */
     int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */

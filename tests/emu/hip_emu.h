@@ -182,6 +182,7 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
