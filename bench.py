@@ -164,6 +164,8 @@ def main():
                                         ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream()), "dss_step_attempt")
             ev.append((a, b, c, d))
             n = E.be.read_int(E.arr["n_active"])
+            if n & (1 << 30):
+                E._raise_overflow()
             k += 1
         return k
 

@@ -30,9 +30,8 @@ def sources():
 # Per-source flags.  The backward kernels differentiate with forward-mode dual numbers whose seeds are compile-time
 # constants after unrolling; letting the compiler assume finite values and ignore the sign of zero is what allows it
 # to fold the arithmetic on derivative slots that are identically zero (0 * x, x + 0).  Values are not reassociated.
-PER_FILE_FLAGS = {
-    "step_bwd.hip": ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"],
-}
+_BWD_FLAGS = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]
+PER_FILE_FLAGS = {"step_bwd.hip": _BWD_FLAGS, "step_bwd_all.hip": _BWD_FLAGS}
 
 
 def build(force=False, verbose=False):
@@ -54,7 +53,10 @@ def build(force=False, verbose=False):
         name = os.path.basename(src)
         obj = os.path.join(objdir, name[:-4] + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hnew):
+        dep = os.path.getmtime(src)
+        if name.endswith("_all.hip"):      # second compilation of <base>.hip with every primitive SDF (see narrowphase.hip)
+            dep = max(dep, os.path.getmtime(os.path.join(CSRC, name[:-8] + ".hip")))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(dep, hnew):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"] + extra + \
             PER_FILE_FLAGS.get(name, []) + ["-c", "-o", obj, src]

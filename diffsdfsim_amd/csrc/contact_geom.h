@@ -5,6 +5,11 @@
 #include "geom.h"
 
 namespace dss {
+#if DSS_ALL_SHAPES
+inline namespace shapes_all {
+#else
+inline namespace shapes_lean {
+#endif
 
 template <class T> struct BodyG {
     T q[4], pos[3];
@@ -19,6 +24,9 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
     sd.type = s.type;
     for (int i = 0; i < 3; ++i) { sd.prm[i] = val(s.prm[i]); sd.hd[i] = val(s.hd[i]); }
     sd.scale = val(s.scale);
+#if DSS_ALL_SHAPES
+    sd.hr = val(s.hr);
+#endif
     double acc = 0.0, pt[3] = {val(p[0]), val(p[1]), val(p[2])}, g[3];
     for (int i = 0; i < 3; ++i) {
         double a, b, save = pt[i];
@@ -153,4 +161,5 @@ template <class T> __host__ __device__ inline void friction_dirs(const T *n, int
     }
 }
 
+}  // inline namespace shapes_*
 }  // namespace dss

@@ -274,40 +274,120 @@ template <class T> __host__ __device__ inline void world_inertia(const T *q, con
         for (int b = 0; b < 3; ++b) out[3 * a + b] = t[3 * a] * R[3 * b] + t[3 * a + 1] * R[3 * b + 1] + t[3 * a + 2] * R[3 * b + 2];
 }
 
-// ---- primitive SDFs (physics3d/bodies.py:38-95) and SDF3D.query_sdfs (:721-760) -------------
-enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2 };
+// ---- primitive SDFs (physics3d/bodies.py:38-185) and SDF3D.query_sdfs (:721-760) ------------
+// The stepper's two hot kernels (narrow phase, contact adjoint) are compiled twice: a lean variant that knows only box /
+// sphere / cylinder (DSS_ALL_SHAPES 0: the remaining primitives cost it registers it does not have) and a variant with
+// every primitive, picked at launch by DssWorld.shape_rare.  The shape code sits in an inline namespace per variant, so
+// the two sets of inline functions are distinct entities.
+#ifndef DSS_ALL_SHAPES
+#define DSS_ALL_SHAPES 1
+#endif
+#if DSS_ALL_SHAPES
+inline namespace shapes_all {
+#else
+inline namespace shapes_lean {
+#endif
+enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2, SHAPE_BOX_ROUNDED = 3, SHAPE_BRICK = 4, SHAPE_BOWL = 5 };
 
 template <class T> struct Shape {
     int type;
-    T prm[3];   // box: dims ; sphere: rad ; cylinder: rad, height (axis = body z)
-    T scale;    // box: 1.5*max(dims)/2 ; sphere: 1.5*rad   (bodies.py:782, 987)
-    T hd[3];    // box: (dims/scale)/2 ; sphere: hd[0] = rad/scale   (hoisted: invariant per body)
+    T prm[3];   // box / rounded box / brick: dims ; sphere: rad ; cylinder: rad, height (axis = body z) ; bowl: r, d
+    T scale;    // box family: 1.5*max(dims)/2 ; sphere: 1.5*rad ; cylinder: 1.5*max(rad, height/2) ; bowl: 1.3333*(r+d)
+    T hd[3];    // unit-frame constants hoisted out of the queries (invariant per body), see make_shape
+#if DSS_ALL_SHAPES
+    T hr;       // rounded box / brick: corner radius / scale
+#endif
 };
-template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int type, const T *prm)
+// aux: the corner radius r of SDFBoxRounded / SDFBrick (a constant of the body; bodies.py:857-885), unused otherwise
+template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int type, const T *prm, double aux = 0.0)
 {
     s.type = type;
     for (int i = 0; i < 3; ++i) s.prm[i] = prm[i];
+#if DSS_ALL_SHAPES
+    s.hr = T(0.0);
+#endif
     if (type == SHAPE_BOX) {
         s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
         for (int i = 0; i < 3; ++i) s.hd[i] = (prm[i] / s.scale) / 2.0;
+#if DSS_ALL_SHAPES
+    } else if (type == SHAPE_BOX_ROUNDED) {   // bodies.py:857-870: params r/scale, (dims - 2 r)/scale -> box_sdf halves them
+        s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
+        for (int i = 0; i < 3; ++i) s.hd[i] = ((prm[i] - 2.0 * aux) / s.scale) / 2.0;
+        s.hr = T(aux) / s.scale;
+    } else if (type == SHAPE_BRICK) {         // bodies.py:873-885, brick_sdf :161-163: half_dims = dims/2 ; half_dims[:2] -= r
+        s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
+        s.hr = T(aux) / s.scale;
+        for (int i = 0; i < 3; ++i) s.hd[i] = (prm[i] / s.scale) / 2.0;
+        s.hd[0] = s.hd[0] - s.hr; s.hd[1] = s.hd[1] - s.hr;
+#endif
     } else if (type == SHAPE_CYLINDER) {   // bodies.py:913-921: scale = 1.5 max(rad, height/2), params rad/scale, height/scale
         s.scale = t_max(prm[0], prm[1] / 2.0) * 1.5;
         s.hd[0] = prm[0] / s.scale; s.hd[1] = (prm[1] / s.scale) / 2.0; s.hd[2] = T(0.0);
+#if DSS_ALL_SHAPES
+    } else if (type == SHAPE_BOWL) {       // bodies.py:1013-1027: scale = (r + d) * 1.3333, params r/scale, d/scale
+        s.scale = (prm[0] + prm[1]) * 1.3333;
+        s.hd[0] = prm[0] / s.scale; s.hd[1] = prm[1] / s.scale; s.hd[2] = T(0.0);
+#endif
     } else {
         s.scale = prm[0] * 1.5;
         s.hd[0] = prm[0] / s.scale; s.hd[1] = T(0.0); s.hd[2] = T(0.0);
     }
 }
 
+#if DSS_ALL_SHAPES
+// the same in the reference's unit frame: pu = the body's parameters / scale, au = r / scale (what the reference hands to
+// sdf_func as *params, up to its own grouping: rounded box (r/scale, (dims - 2 r)/scale))
+template <class T> __host__ __device__ inline void make_unit_shape(Shape<T> &s, int type, const T *pu, const T &au)
+{
+    s.type = type;
+    for (int i = 0; i < 3; ++i) { s.prm[i] = pu[i]; s.hd[i] = T(0.0); }
+    s.scale = T(1.0);
+    s.hr = au;
+    if (type == SHAPE_BOX) for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0;          // box_sdf: half_dims = dims / 2
+    else if (type == SHAPE_BOX_ROUNDED) for (int i = 0; i < 3; ++i) s.hd[i] = (pu[i] - au * 2.0) / 2.0;
+    else if (type == SHAPE_BRICK) { for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0; s.hd[0] = s.hd[0] - au; s.hd[1] = s.hd[1] - au; }
+    else if (type == SHAPE_CYLINDER) { s.hd[0] = pu[0]; s.hd[1] = pu[1] / 2.0; }
+    else if (type == SHAPE_BOWL) { s.hd[0] = pu[0]; s.hd[1] = pu[1]; }
+    else s.hd[0] = pu[0];
+}
+
+// box_sdf_grad (bodies.py:51-72) for half extents hd: failsafe diagonal normals on ties; normalised twice
+// (once by the function, once more by query_sdfs, bodies.py:748)
+template <class T> __host__ __device__ __forceinline__ void box_unit_grad(const T *p, const T *hd, T *g)
+{
+    T q[3], mg[3], nm[3], go[3];
+    for (int i = 0; i < 3; ++i) q[i] = t_abs(p[i]) - hd[i];
+    const T md = t_max(t_max(q[0], q[1]), q[2]);
+    for (int i = 0; i < 3; ++i) mg[i] = t_maximum(q[i], T(0.0));   // torch.max(q, zeros): ties split
+    normalize(mg, nm);
+    for (int i = 0; i < 3; ++i) {
+        const double sg = val(p[i]) < 0.0 ? -1.0 : 1.0;
+        const double md_dir = (val(md) <= 0.0 && val(q[i]) == val(md)) ? 1.0 : 0.0;
+        go[i] = (nm[i] + md_dir) * sg;
+    }
+    T g1[3];
+    normalize(go, g1);
+    normalize(g1, g);
+}
+
+#endif
+
 // value and (normalised) gradient of the unit-cube SDF at p = pts/scale, parameters prm/scale
 template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, const T *p, T &phi, T *g, bool want_grad)
 {
+#if DSS_ALL_SHAPES
+    if (s.type == SHAPE_BOX || s.type == SHAPE_BOX_ROUNDED) {
+#else
     if (s.type == SHAPE_BOX) {
+#endif
         T q[3], m[3];
         for (int i = 0; i < 3; ++i) q[i] = t_abs(p[i]) - s.hd[i];
         const T md = t_max(t_max(q[0], q[1]), q[2]);
         for (int i = 0; i < 3; ++i) m[i] = t_clamp_min(q[i], 0.0);
         phi = norm3(m) + t_clamp_max(md, 0.0);
+#if DSS_ALL_SHAPES
+        if (s.type == SHAPE_BOX_ROUNDED) phi = phi - s.hr;   // rounded_sdf (bodies.py:139-145); gradient of the base box
+#endif
         if (want_grad) {
             // box_sdf_grad: failsafe diagonal normals on ties (bodies.py:51-72); m = max(q, 0)
             T mg[3], nm[3], go[3];
@@ -342,6 +422,52 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
             normalize(go, g1n);
             normalize(g1n, g);  // query_sdfs normalises again (bodies.py:748)
         }
+#if DSS_ALL_SHAPES
+    } else if (s.type == SHAPE_BRICK) {
+        // brick_sdf (bodies.py:160-177): rounded rectangle in (x, y), then a 2-D box of (that distance, |z| - hz)
+        const T q0 = t_abs(p[0]) - s.hd[0], q1 = t_abs(p[1]) - s.hd[1], q2 = t_abs(p[2]) - s.hd[2];
+        const T md01 = t_max(q0, q1);
+        const T m0 = t_clamp_min(q0, 0.0), m1 = t_clamp_min(q1, 0.0);
+        const T s01 = t_sqrt(m0 * m0 + m1 * m1) + t_clamp_max(md01, 0.0) - s.hr;
+        const T md = t_max(s01, q2);
+        const T n0 = t_clamp_min(s01, 0.0), n1 = t_clamp_min(q2, 0.0);
+        phi = t_sqrt(n0 * n0 + n1 * n1) + t_clamp_max(md, 0.0);
+        if (want_grad) {
+            // SDFBrick passes grad_func = rounded_sdf_grad(box_sdf_grad) with params (dims/scale, r/scale): the wrapper
+            // drops its FIRST parameter, so the reference's normal is box_sdf_grad(pts, r/scale), a cube of side
+            // r/scale (bodies.py:148-154, 881-883).  Restated as is.
+            const T h = s.hr / 2.0, hh[3] = {h, h, h};
+            box_unit_grad(p, hh, g);
+        }
+    } else if (s.type == SHAPE_BOWL) {
+        // bowl_sdf / bowl_sdf_grad (bodies.py:98-136).  Both shift pts[:, 2] by r/2 IN PLACE and query_sdfs hands them the
+        // same tensor (bodies.py:746-748), so the gradient is evaluated at a point shifted twice.  Restated as is.
+        const T r = s.hd[0], d = s.hd[1];
+        const T z = p[2] - r / 2.0;
+        const T rho = t_sqrt(p[0] * p[0] + p[1] * p[1]);
+        {
+            const T pn = t_sqrt(rho * rho + z * z);
+            T a = val(z) < 0.0 ? pn : rho;
+            a = t_abs(a - r) - d;
+            const T m0 = t_maximum(a, T(0.0)), m1 = t_maximum(z, T(0.0));
+            phi = t_sqrt(m0 * m0 + m1 * m1) + t_min(T(0.0), t_max(a, z));
+        }
+        if (want_grad) {
+            const T z2 = z - r / 2.0;
+            const T pn = t_sqrt(rho * rho + z2 * z2);
+            T a = val(z2) < 0.0 ? pn : rho;
+            a = t_abs(a - r) - d;
+            const double dv = val(pn) - val(r), sg = dv > 0.0 ? 1.0 : (dv < 0.0 ? -1.0 : 0.0);
+            T go[3] = {p[0] * sg, p[1] * sg, z2 * sg};
+            if (val(z2) >= 0.0) {
+                if (val(a) < 0.0) { go[0] = T(0.0); go[1] = T(0.0); }
+                go[2] = t_abs(go[2]);
+            }
+            T g1[3];
+            normalize(go, g1);
+            normalize(g1, g);
+        }
+#endif
     } else {
         const T n = norm3(p);
         phi = n - s.hd[0];
@@ -367,4 +493,5 @@ template <class T> __host__ __device__ inline bool query_sdf(const Shape<T> &s, 
     return true;
 }
 
+}  // inline namespace shapes_*
 }  // namespace dss

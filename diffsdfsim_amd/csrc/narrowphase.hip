@@ -18,6 +18,14 @@
 // The reference thins each normal cluster with Qhull (3-D hull, falling back to 2-D / 1-D when the
 // points are flat).  Here: flatness tests with the same fall-back order, a gift-wrapping hull in
 // 2-D (collinear points dropped), min/max in 1-D and a supporting-plane test in 3-D.
+// This file is compiled twice: as is (DSS_ALL_SHAPES 0, the lean variant the benchmark configs run: box / sphere / cylinder
+// bodies with their analytic meshes) and through narrowphase_all.hip (DSS_ALL_SHAPES 1, the full variant: every primitive,
+// and the hull stage prepared for level-set meshes -- coincident contact points, normal clusters beyond the LDS scratch;
+// only launch_find_contacts_all is exported).  DssWorld.shape_rare picks the variant at launch.  The lean kernel sits at a
+// register-allocation equilibrium: the full variant's extra code costs it 25 %.
+#ifndef DSS_ALL_SHAPES
+#define DSS_ALL_SHAPES 0
+#endif
 #include <math.h>
 #include <stdlib.h>
 
@@ -29,7 +37,7 @@ namespace {
 using namespace dss;
 
 constexpr int NT = 256;
-constexpr int MAX_CPT = 8;       // candidates per thread: max_cand <= NT * MAX_CPT
+constexpr int MAX_CPT = 8;       // moving candidates per thread of a group: HCAP <= BT * MAX_CPT
 constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
 constexpr int WAVE_ITEM_MAX_FACES = 32 * 256;   // items that search a bigger mesh take a whole workgroup (WaveGroup::CHCAP runs)
 
@@ -52,7 +60,11 @@ __device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
     for (int i = 0; i < 4; ++i) o.g.q[i] = ps[i];
     for (int i = 0; i < 3; ++i) o.g.pos[i] = ps[4 + i];
     const double *prm = W.shape_prm + ((size_t)sc * W.nb + b) * 3;
+#if DSS_ALL_SHAPES
+    make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm, W.shape_aux[(size_t)sc * W.nb + b]);
+#else
     make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm);
+#endif
     // the same for every lane: keep it in scalar registers (frees ~60 VGPRs in the narrow phase)
     for (int i = 0; i < 4; ++i) o.g.q[i] = dss_uniform(o.g.q[i]);
     for (int i = 0; i < 3; ++i) {
@@ -61,6 +73,9 @@ __device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
         o.g.shape.hd[i] = dss_uniform(o.g.shape.hd[i]);
     }
     o.g.shape.scale = dss_uniform(o.g.shape.scale);
+#if DSS_ALL_SHAPES
+    o.g.shape.hr = dss_uniform(o.g.shape.hr);
+#endif
     o.g.shape.type = dss_uniform(o.g.shape.type);
     o.mesh = W.mesh_id[(size_t)sc * W.nb + b];
     o.voff = W.mesh_voff[o.mesh]; o.nv = W.mesh_nv[o.mesh];
@@ -296,48 +311,64 @@ template <class G> __device__ inline double block_sum(double v, ScratchT<G> &S)
 // ---- hull of one normal cluster (points in S.hp, m of them); marks S.hflag ---------------------
 // Mirrors the fall-back ladder of contacts.py:126-152: 3-D hull; if Qhull would reject the input as
 // flat drop the coordinate of least variance and retry in 2-D; then 1-D min/max.
-template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double eps)
+// where a cluster's points and keep-flags live while its hull is taken: in LDS (clusters of up to HCAP points) or, for the
+// clusters a level-set mesh resting flat on a neighbour produces (every face of the resting side), in the group's global
+// candidate scratch (rows 3-6 of cand_buf, dead after the contact geometry stage)
+template <class G> struct HullLds {
+    ScratchT<G> *S;
+    __device__ inline double hp(int k, int d) const { return S->hp[3 * k + d]; }
+    __device__ inline int getf(int k) const { return S->hflag[k]; }
+    __device__ inline void setf(int k, int v) const { S->hflag[k] = (unsigned char)v; }
+};
+struct HullGlobal {
+    double *cb; int mc;
+    __device__ inline double hp(int k, int d) const { return cb[(size_t)(3 + d) * mc + k]; }
+    __device__ inline int getf(int k) const { return (int)cb[(size_t)6 * mc + k]; }
+    __device__ inline void setf(int k, int v) const { cb[(size_t)6 * mc + k] = (double)v; }
+};
+
+template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
 {
     const int tid = G::tid();
-    for (int k = tid; k < m; k += G::BT) S.hflag[k] = 0;
+    for (int k = tid; k < m; k += G::BT) P.setf(k, 0);
     G::sync();
-    if (m == 1) { if (tid == 0) S.hflag[0] = 1; G::sync(); return; }
+    if (m == 1) { if (tid == 0) P.setf(0, 1); G::sync(); return; }
     // per-coordinate mean / unbiased variance (torch.var)
     double mean[3], var[3], amax = 0.0;
     for (int d = 0; d < 3; ++d) {
         double acc = 0.0, mx = 0.0;
-        for (int k = tid; k < m; k += G::BT) { acc += S.hp[3 * k + d]; mx = fmax(mx, fabs(S.hp[3 * k + d])); }
+        for (int k = tid; k < m; k += G::BT) { acc += P.hp(k, d); mx = fmax(mx, fabs(P.hp(k, d))); }
         mean[d] = block_sum(acc, S) / m;
         amax = fmax(amax, block_max(mx, S));
         acc = 0.0;
-        for (int k = tid; k < m; k += G::BT) { const double t = S.hp[3 * k + d] - mean[d]; acc += t * t; }
+        for (int k = tid; k < m; k += G::BT) { const double t = P.hp(k, d) - mean[d]; acc += t * t; }
         var[d] = block_sum(acc, S) / (m - 1);
     }
     const double tolf = 1e-12 * (1.0 + amax);
     // farthest point B from A = point 0, then C farthest from line AB
-    const double *A = S.hp;
+    const double A[3] = {P.hp(0, 0), P.hp(0, 1), P.hp(0, 2)};
     double key = -1.0; int ki = -1;
     for (int k = tid; k < m; k += G::BT) {
-        const double d0 = S.hp[3 * k] - A[0], d1 = S.hp[3 * k + 1] - A[1], d2 = S.hp[3 * k + 2] - A[2];
+        const double d0 = P.hp(k, 0) - A[0], d1 = P.hp(k, 1) - A[1], d2 = P.hp(k, 2) - A[2];
         const double dd = d0 * d0 + d1 * d1 + d2 * d2;
         if (dd > key) { key = dd; ki = k; }
     }
     const int iB = block_argmin(-key, ki, S);
-    double ab[3] = {S.hp[3 * iB] - A[0], S.hp[3 * iB + 1] - A[1], S.hp[3 * iB + 2] - A[2]};
+    double ab[3] = {P.hp(iB, 0) - A[0], P.hp(iB, 1) - A[1], P.hp(iB, 2) - A[2]};
     const double lab = sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
     bool flat3 = (m < 4) || !(lab > tolf), line = !(lab > tolf);
     double nrm[3] = {0, 0, 0};
     if (!line) {
         key = -1.0; ki = -1;
         for (int k = tid; k < m; k += G::BT) {
-            const double d[3] = {S.hp[3 * k] - A[0], S.hp[3 * k + 1] - A[1], S.hp[3 * k + 2] - A[2]};
+            const double d[3] = {P.hp(k, 0) - A[0], P.hp(k, 1) - A[1], P.hp(k, 2) - A[2]};
             double c[3];
             cross(ab, d, c);
             const double dd = (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
             if (dd > key) { key = dd; ki = k; }
         }
         const int iC = block_argmin(-key, ki, S);
-        const double ac[3] = {S.hp[3 * iC] - A[0], S.hp[3 * iC + 1] - A[1], S.hp[3 * iC + 2] - A[2]};
+        const double ac[3] = {P.hp(iC, 0) - A[0], P.hp(iC, 1) - A[1], P.hp(iC, 2) - A[2]};
         cross(ab, ac, nrm);
         const double ln = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
         if (!(ln / lab > tolf)) { line = true; flat3 = true; }
@@ -345,27 +376,66 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
             for (int d = 0; d < 3; ++d) nrm[d] /= ln;
             double mx = -INFINITY, mn = INFINITY; int imx = -1, imn = -1;
             for (int k = tid; k < m; k += G::BT) {
-                const double sd = nrm[0] * (S.hp[3 * k] - A[0]) + nrm[1] * (S.hp[3 * k + 1] - A[1]) + nrm[2] * (S.hp[3 * k + 2] - A[2]);
+                const double sd = nrm[0] * (P.hp(k, 0) - A[0]) + nrm[1] * (P.hp(k, 1) - A[1]) + nrm[2] * (P.hp(k, 2) - A[2]);
                 if (sd > mx) { mx = sd; imx = k; }
                 if (sd < mn) { mn = sd; imn = k; }
             }
             const int gmx = block_argmin(-mx, imx, S), gmn = block_argmin(mn, imn, S);
-            const double dmx = nrm[0] * (S.hp[3 * gmx] - A[0]) + nrm[1] * (S.hp[3 * gmx + 1] - A[1]) + nrm[2] * (S.hp[3 * gmx + 2] - A[2]);
-            const double dmn = nrm[0] * (S.hp[3 * gmn] - A[0]) + nrm[1] * (S.hp[3 * gmn + 1] - A[1]) + nrm[2] * (S.hp[3 * gmn + 2] - A[2]);
+            const double dmx = nrm[0] * (P.hp(gmx, 0) - A[0]) + nrm[1] * (P.hp(gmx, 1) - A[1]) + nrm[2] * (P.hp(gmx, 2) - A[2]);
+            const double dmn = nrm[0] * (P.hp(gmn, 0) - A[0]) + nrm[1] * (P.hp(gmn, 1) - A[1]) + nrm[2] * (P.hp(gmn, 2) - A[2]);
             const double thick = fmax(fabs(dmx), fabs(dmn));
             if (!(thick > tolf)) flat3 = true;
             else if (thick <= 1e-6 * (1.0 + amax) && m >= 4) {
                 // a sliver: its 3-D hull is the 2-D hull of the projection plus the points that stick out of
                 // the plane (Qhull keeps those as vertices; anything flatter than round-off it rejects outright)
                 flat3 = true;
-                if (tid == 0) { if (fabs(dmx) > tolf) S.hflag[gmx] = 2; if (fabs(dmn) > tolf) S.hflag[gmn] = 2; }   // 2 = kept, not a visited hull vertex
+                if (tid == 0) { if (fabs(dmx) > tolf) P.setf(gmx, 2); if (fabs(dmn) > tolf) P.setf(gmn, 2); }   // 2 = kept, not a visited hull vertex
                 G::sync();
             }
         }
     }
+#if DSS_ALL_SHAPES
+    if (!flat3 && m > 2048) {   // beyond what the pairwise duplicate search below is meant for: keep every point
+        for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
+        G::sync();
+        return;
+    }
+    if (!flat3) {
+        // Coincident points (candidates of neighbouring faces that converged to a shared mesh vertex -- the rule on a
+        // level-set mesh) are one hull vertex to Qhull: the first of each group stands for it.  3 = duplicate.
+        for (int k = tid; k < m; k += G::BT) {
+            int dup = 0;
+            for (int j = 0; j < k && !dup; ++j) {
+                const double d0 = P.hp(k, 0) - P.hp(j, 0), d1 = P.hp(k, 1) - P.hp(j, 1), d2 = P.hp(k, 2) - P.hp(j, 2);
+                dup = !(d0 * d0 + d1 * d1 + d2 * d2 > tolf * tolf);
+            }
+            if (dup) P.setf(k, 3);
+        }
+        G::sync();
+        static_assert(HULL3_MAX <= 64, "the list of distinct points lives in red_i");
+        if (tid == 0) {
+            int mu = 0;
+            for (int k = 0; k < m; ++k) if (P.getf(k) != 3) { if (mu < HULL3_MAX) S.red_i[mu] = k; ++mu; }
+            S.wave_tot[0] = mu;
+        }
+        G::sync();
+        const int mu = S.wave_tot[0];
+        G::sync();
+        if (mu > HULL3_MAX) {  // beyond the brute-force limit: keep every distinct point (superset of the hull)
+            for (int k = tid; k < m; k += G::BT) P.setf(k, P.getf(k) == 3 ? 0 : 1);
+            G::sync();
+            return;
+        }
+        // supporting-plane test over all triples of distinct points
+        const int ntri = mu * mu * mu;
+        for (int e = tid; e < ntri; e += G::BT) {
+            const int iu = e / (mu * mu), ju = (e / mu) % mu, ku = e % mu;
+            if (!(iu < ju && ju < ku)) continue;
+            const int i = S.red_i[iu], j = S.red_i[ju], k = S.red_i[ku];
+#else
     if (!flat3) {
         if (m > HULL3_MAX) {  // beyond the brute-force limit: keep every point (superset of the hull)
-            for (int k = tid; k < m; k += G::BT) S.hflag[k] = 1;
+            for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
             G::sync();
             return;
         }
@@ -374,20 +444,25 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
         for (int e = tid; e < ntri; e += G::BT) {
             const int i = e / (m * m), j = (e / m) % m, k = e % m;
             if (!(i < j && j < k)) continue;
-            const double u[3] = {S.hp[3 * j] - S.hp[3 * i], S.hp[3 * j + 1] - S.hp[3 * i + 1], S.hp[3 * j + 2] - S.hp[3 * i + 2]};
-            const double v[3] = {S.hp[3 * k] - S.hp[3 * i], S.hp[3 * k + 1] - S.hp[3 * i + 1], S.hp[3 * k + 2] - S.hp[3 * i + 2]};
+#endif
+            const double u[3] = {P.hp(j, 0) - P.hp(i, 0), P.hp(j, 1) - P.hp(i, 1), P.hp(j, 2) - P.hp(i, 2)};
+            const double v[3] = {P.hp(k, 0) - P.hp(i, 0), P.hp(k, 1) - P.hp(i, 1), P.hp(k, 2) - P.hp(i, 2)};
             double n[3];
             cross(u, v, n);
             const double ln = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             if (!(ln > 1e-14 * (1.0 + amax) * (1.0 + amax))) continue;
             int pos = 0, neg = 0;
             for (int q = 0; q < m; ++q) {
-                const double sd = (n[0] * (S.hp[3 * q] - S.hp[3 * i]) + n[1] * (S.hp[3 * q + 1] - S.hp[3 * i + 1]) + n[2] * (S.hp[3 * q + 2] - S.hp[3 * i + 2])) / ln;
+                const double sd = (n[0] * (P.hp(q, 0) - P.hp(i, 0)) + n[1] * (P.hp(q, 1) - P.hp(i, 1)) + n[2] * (P.hp(q, 2) - P.hp(i, 2))) / ln;
                 pos |= sd > tolf; neg |= sd < -tolf;
             }
-            if (!(pos && neg)) { S.hflag[i] = 1; S.hflag[j] = 1; S.hflag[k] = 1; }
+            if (!(pos && neg)) { P.setf(i, 1); P.setf(j, 1); P.setf(k, 1); }
         }
         G::sync();
+#if DSS_ALL_SHAPES
+        for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
+        G::sync();
+#endif
         return;
     }
     // ---- 2-D: drop the coordinate of least variance (first index on ties, torch.argmin) ---------
@@ -400,26 +475,26 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
     if (!collinear) {
         // start: lexicographic minimum
         double k0 = INFINITY; int k0i = -1;
-        for (int k = tid; k < m; k += G::BT) if (S.hp[3 * k + c0] < k0) { k0 = S.hp[3 * k + c0]; k0i = k; }
+        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) < k0) { k0 = P.hp(k, c0); k0i = k; }
         const int i0 = block_argmin(k0, k0i, S);
-        const double x0 = S.hp[3 * i0 + c0];
+        const double x0 = P.hp(i0, c0);
         k0 = INFINITY; k0i = -1;
-        for (int k = tid; k < m; k += G::BT) if (S.hp[3 * k + c0] == x0 && S.hp[3 * k + c1] < k0) { k0 = S.hp[3 * k + c1]; k0i = k; }
+        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) == x0 && P.hp(k, c1) < k0) { k0 = P.hp(k, c1); k0i = k; }
         iS = block_argmin(k0, k0i, S);
         // collinearity: farthest point from the start, then max distance to that line
         key = -1.0; ki = -1;
         for (int k = tid; k < m; k += G::BT) {
-            const double d0 = S.hp[3 * k + c0] - S.hp[3 * iS + c0], d1 = S.hp[3 * k + c1] - S.hp[3 * iS + c1];
+            const double d0 = P.hp(k, c0) - P.hp(iS, c0), d1 = P.hp(k, c1) - P.hp(iS, c1);
             if (d0 * d0 + d1 * d1 > key) { key = d0 * d0 + d1 * d1; ki = k; }
         }
         const int iF = block_argmin(-key, ki, S);
-        const double e0 = S.hp[3 * iF + c0] - S.hp[3 * iS + c0], e1 = S.hp[3 * iF + c1] - S.hp[3 * iS + c1];
+        const double e0 = P.hp(iF, c0) - P.hp(iS, c0), e1 = P.hp(iF, c1) - P.hp(iS, c1);
         const double le = sqrt(e0 * e0 + e1 * e1);
         if (!(le > tolf)) collinear = true;
         else {
             double mx = 0.0;
             for (int k = tid; k < m; k += G::BT)
-                mx = fmax(mx, fabs(e0 * (S.hp[3 * k + c1] - S.hp[3 * iS + c1]) - e1 * (S.hp[3 * k + c0] - S.hp[3 * iS + c0])) / le);
+                mx = fmax(mx, fabs(e0 * (P.hp(k, c1) - P.hp(iS, c1)) - e1 * (P.hp(k, c0) - P.hp(iS, c0))) / le);
             if (!(block_max(mx, S) > tolf)) collinear = true;
         }
     }
@@ -427,11 +502,11 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
         // gift wrapping, counter-clockwise; collinear candidates: the farthest wins (interior ones dropped)
         int cur = iS;
         for (int step = 0; step < m; ++step) {
-            if (tid == 0) S.hflag[cur] = 1;
-            const double cx = S.hp[3 * cur + c0], cy = S.hp[3 * cur + c1];
+            if (tid == 0) P.setf(cur, 1);
+            const double cx = P.hp(cur, c0), cy = P.hp(cur, c1);
             int best = -1; double bx = 0, by = 0;
             for (int k = tid; k < m; k += G::BT) {
-                const double qx = S.hp[3 * k + c0] - cx, qy = S.hp[3 * k + c1] - cy;
+                const double qx = P.hp(k, c0) - cx, qy = P.hp(k, c1) - cy;
                 const double lq = qx * qx + qy * qy;
                 if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
                 if (best < 0) { best = k; bx = qx; by = qy; continue; }
@@ -449,8 +524,8 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
                     if (b >= 0) {
                         if (a < 0) S.red_i[tid] = b;
                         else {
-                            const double ax = S.hp[3 * a + c0] - cx, ay = S.hp[3 * a + c1] - cy;
-                            const double qx = S.hp[3 * b + c0] - cx, qy = S.hp[3 * b + c1] - cy;
+                            const double ax = P.hp(a, c0) - cx, ay = P.hp(a, c1) - cy;
+                            const double qx = P.hp(b, c0) - cx, qy = P.hp(b, c1) - cy;
                             const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
                             const double c2 = cr * cr, t2 = 1e-18 * (la * lq);
                             if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
@@ -460,11 +535,11 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
                 G::sync();
             }
             const int nxt = S.red_i[0];
-            const int seen = nxt >= 0 ? (S.hflag[nxt] == 1) : 0;
+            const int seen = nxt >= 0 ? (P.getf(nxt) == 1) : 0;
             G::sync();   // every thread has read red_i / hflag before thread 0 flags the next vertex
             if (nxt < 0 || nxt == iS || seen) break;
             {   // coincident with the start (shared mesh vertices produce exact duplicates): the loop is closed
-                const double dx = S.hp[3 * nxt + c0] - S.hp[3 * iS + c0], dy = S.hp[3 * nxt + c1] - S.hp[3 * iS + c1];
+                const double dx = P.hp(nxt, c0) - P.hp(iS, c0), dy = P.hp(nxt, c1) - P.hp(iS, c1);
                 if (!(dx * dx + dy * dy > tolf * tolf)) break;
             }
             cur = nxt;
@@ -476,14 +551,14 @@ template <class G> __device__ void cluster_hull(ScratchT<G> &S, int m, double ep
     const int keep = (var[c1] < var[c0]) ? c0 : c1;  // argmin over the remaining two drops the smaller
     double kmin = INFINITY, kmax = -INFINITY; int imin = -1, imax = -1;
     for (int k = tid; k < m; k += G::BT) {
-        const double v = S.hp[3 * k + keep];
+        const double v = P.hp(k, keep);
         if (v < kmin) { kmin = v; imin = k; }
         if (v > kmax) { kmax = v; imax = k; }
     }
     const int gmin = block_argmin(kmin, imin, S), gmax = block_argmin(-kmax, imax, S);
     if (tid == 0) {
-        S.hflag[gmin] = 1;
-        if (S.hp[3 * gmax + keep] - S.hp[3 * gmin + keep] > eps) S.hflag[gmax] = 1;
+        P.setf(gmin, 1);
+        if (P.hp(gmax, keep) - P.hp(gmin, keep) > eps) P.setf(gmax, 1);
     }
     G::sync();
 }
@@ -930,6 +1005,36 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
                     const double d = fmin(nk[0] * sn[0] + nk[1] * sn[1] + nk[2] * sn[2], 1.0);
                     in = acos(d) < 1e-2;
                 }
+#if DSS_ALL_SHAPES
+                const int slot = compact_slot(in, m, S);
+                if (slot >= 0) {
+                    set_state(k, 3);     // member of the cluster being thinned
+                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = p1v[i]; }
+                }
+            }
+            G::sync();
+            if (m <= G::HCAP) {
+                cluster_hull(S, HullLds<G>{&S}, m, W.eps);
+                for (int j = tid; j < m; j += G::BT) set_state(S.hidx[j], S.hflag[j] ? 2 : 1);
+            } else {
+                // more points than the LDS scratch holds (a level-set mesh lying flat on its neighbour: every face of that
+                // side is a contact with the same normal): gather the members again, into the global candidate scratch
+                if (G::BT == 64) return 1;
+                m = 0;
+                for (int base = 0; base < ncon; base += G::BT) {
+                    const int k = base + tid;
+                    const int in = k < ncon && get_state(k) == 3;
+                    const int slot = compact_slot(in, m, S);
+                    if (slot >= 0) { cface[slot] = k; for (int i = 0; i < 3; ++i) CB(3 + i, slot) = CB(21 + i, k); }
+                }
+                G::sync();
+                const HullGlobal P{cb, MC};
+                cluster_hull(S, P, m, W.eps);
+                for (int j = tid; j < m; j += G::BT) set_state(cface[j], P.getf(j) ? 2 : 1);
+            }
+            G::sync();
+        }
+#else
                 const int slot = compact_slot(in, m, S);
                 if (slot >= 0) {
                     set_state(k, 1);
@@ -938,10 +1043,11 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             }
             G::sync();
             if (m > G::HCAP) { if (G::BT == 64) return 1; over |= 2; m = G::HCAP; }
-            cluster_hull(S, m, W.eps);
+            cluster_hull(S, HullLds<G>{&S}, m, W.eps);
             for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) set_state(S.hidx[j], 2);
             G::sync();
         }
+#endif
         for (int k = tid, r = 0; k < ncon; k += G::BT, ++r) {
             const int kept = get_state(k) == 2;
             keptbits |= (unsigned)kept << r;     // round r of this thread: the final stage walks the same (round, thread) grid
@@ -1099,10 +1205,20 @@ static inline int np_grid(int B, int nb)
     return (int)(items < 256 * DSS_NP_WAVES ? items : 256 * DSS_NP_WAVES);
 }
 // enqueue detection at the current pose; results land in (nc_out, body_out, ...)
+#if DSS_ALL_SHAPES
+int launch_find_contacts_all(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
+                             double *geom_out, hipStream_t stream)
+{
+#else
+int launch_find_contacts_all(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
+                             double *geom_out, hipStream_t stream);
 int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
                          double *geom_out, hipStream_t stream)
 {
-    if (W.max_cand > NT * MAX_CPT || W.nb < 1) return DSS_E_UNSUPPORTED;
+    if (W.shape_rare) return launch_find_contacts_all(W, nc_out, body_out, face_out, abc_out, geom_out, stream);
+#endif
+    static_assert(BlockGroup::HCAP <= BlockGroup::BT * MAX_CPT && WaveGroup::HCAP <= WaveGroup::BT * MAX_CPT, "mover registers");
+    if (W.max_cand < 1 || W.nb < 1) return DSS_E_UNSUPPORTED;
     if (W.nb < 2) {   // a single body has nothing to collide with: empty contact lists (the no-contact branch, engines.py:40-54)
         hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
         return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
@@ -1120,4 +1236,6 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
 }
 }  // namespace dss
 
+#if !DSS_ALL_SHAPES
 extern "C" int dss_np_slots(int B, int nb) { return dss::np_grid(B, nb) * 4; }
+#endif

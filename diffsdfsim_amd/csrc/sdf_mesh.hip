@@ -17,14 +17,14 @@
 namespace {
 using namespace dss;
 
-__global__ void __launch_bounds__(256) sdf_query_kernel(int type, double p0, double p1, double p2, const double *pts, int n,
+__global__ void __launch_bounds__(256) sdf_query_kernel(int type, double p0, double p1, double p2, double aux, const double *pts, int n,
                                                        double *sdf, double *grad, unsigned char *mask)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Shape<double> s;
     const double prm[3] = {p0, p1, p2};
-    make_shape(s, type, prm);
+    make_shape(s, type, prm, aux);
     const double pt[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     double phi, g[3] = {0.0, 0.0, 0.0};
     const bool in = query_sdf(s, pt, phi, g, grad != nullptr);
@@ -226,9 +226,9 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
                   unsigned char *overlap_mask, void *stream)
 {
     if (!prm || !pts || !sdf || n <= 0) return DSS_E_BADARG;
-    if (shape_type != DSS_SHAPE_BOX && shape_type != DSS_SHAPE_SPHERE && shape_type != DSS_SHAPE_CYLINDER) return DSS_E_UNSUPPORTED;
+    if (shape_type < DSS_SHAPE_BOX || shape_type > DSS_SHAPE_BOWL) return DSS_E_UNSUPPORTED;
     hipLaunchKernelGGL(sdf_query_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shape_type, prm[0], prm[1],
-                       prm[2], pts, n, sdf, grad, overlap_mask);
+                       prm[2], prm[3], pts, n, sdf, grad, overlap_mask);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 

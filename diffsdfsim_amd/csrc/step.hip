@@ -115,6 +115,9 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
 {
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
     if (!W.active[sc]) return;
+    // a capacity was exceeded in contact detection (sticky, see DssWorld.overflow): tell the host through the word it
+    // reads after every attempt, so that a truncated contact set never goes unnoticed
+    if (lane == 0 && W.overflow[sc]) atomicOr(W.n_active, DSS_N_ACTIVE_OVERFLOW);
     const double dt_try = W.dt_try[sc];
     const bool tiny = !W.strict_no_pen && dt_try < W.dt / 1024.0;   // world.py:345-347
     const bool accept = !W.invalid[sc] || tiny;

@@ -14,6 +14,12 @@
 // Small nonlinear stages are differentiated with forward-mode duals (geom.h) seeded a few inputs at a
 // time and contracted with the incoming adjoint; linear stages are transposed by hand.  Sums over the
 // contacts of a body run in contact order (no atomics): gradients are bit-reproducible.
+//
+// Compiled twice, like narrowphase.hip: as is (box / sphere / cylinder only) and through step_bwd_all.hip (every
+// primitive; exports only launch_bwd_pre_all, which dss_step_backward uses when DssWorld.shape_rare is set).
+#ifndef DSS_ALL_SHAPES
+#define DSS_ALL_SHAPES 0
+#endif
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"
@@ -71,6 +77,11 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     const double *P1 = pose_n + 7 * b1, *P2 = pose_n + 7 * b2;
     const double *prm1 = W.shape_prm + ((size_t)sc * nb + b1) * 3, *prm2 = W.shape_prm + ((size_t)sc * nb + b2) * 3;
     const int ty1 = W.shape_type[(size_t)sc * nb + b1], ty2 = W.shape_type[(size_t)sc * nb + b2];
+#if DSS_ALL_SHAPES
+    const double aux1 = W.shape_aux[(size_t)sc * nb + b1], aux2 = W.shape_aux[(size_t)sc * nb + b2];
+#else
+    const double aux1 = 0.0, aux2 = 0.0;
+#endif
     const int mesh = W.mesh_id[(size_t)sc * nb + b1];
     const int voff = W.mesh_voff[mesh], foff = W.mesh_foff[mesh];
     const int *fv = W.faces + (size_t)(foff + face) * 3;
@@ -84,8 +95,8 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         BodyG<double> B1, B2;
         for (int i = 0; i < 4; ++i) { B1.q[i] = P1[i]; B2.q[i] = P2[i]; }
         for (int i = 0; i < 3; ++i) { B1.pos[i] = P1[4 + i]; B2.pos[i] = P2[4 + i]; }
-        make_shape(B1.shape, ty1, prm1);
-        make_shape(B2.shape, ty2, prm2);
+        make_shape(B1.shape, ty1, prm1, aux1);
+        make_shape(B2.shape, ty2, prm2, aux2);
         double nn[3], pp2[3], pen;
         contact_head(B1, tv, abc, cp1v, n1v, d1v, p1v);
         contact_tail(B1, B2, cp1v, n1v, d1v, p1v, 1e-3, nn, pp2, pen, &stable);
@@ -109,15 +120,15 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
             pr1[i] = D(prm1[i]); if (grp == 1) pr1[i].d[i] = 1.0;
             pr2[i] = D(prm2[i]);
         }
-        make_shape(B1.shape, ty1, pr1);
-        make_shape(B2.shape, ty2, pr2);
+        make_shape(B1.shape, ty1, pr1, aux1);
+        make_shape(B2.shape, ty2, pr2, aux2);
         D tri[3][3];
         for (int v = 0; v < 3; ++v)
             for (int i = 0; i < 3; ++i) {
                 D d(tv[v][i]);
                 if (grp == 1) {
                     // box: own axis; sphere: radius; cylinder: x,y <- rad, z <- height
-                    const int s = (ty1 == SHAPE_BOX) ? i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 1 : 0);
+                    const int s = (ty1 == SHAPE_BOX || ty1 == SHAPE_BOX_ROUNDED || ty1 == SHAPE_BRICK) ? i : ((ty1 == SHAPE_CYLINDER && i == 2) ? 1 : 0);
 #pragma unroll
                     for (int sl = 0; sl < 3; ++sl) if (sl == s) d.d[sl] = tg[v][i];   // selects: a run-time index would put d in scratch
                 }
@@ -140,8 +151,8 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
             pr1[i] = D(prm1[i]);
             pr2[i] = D(prm2[i]); if (grp == 2) pr2[i].d[i] = 1.0;
         }
-        make_shape(B1.shape, ty1, pr1);
-        make_shape(B2.shape, ty2, pr2);
+        make_shape(B1.shape, ty1, pr1, aux1);
+        make_shape(B2.shape, ty2, pr2, aux2);
         D cp1[3], n1[3], d1(d1v), p1[3], n[3], p2[3], pen;
         for (int i = 0; i < 3; ++i) { cp1[i] = D(cp1v[i]); n1[i] = D(n1v[i]); p1[i] = D(p1v[i]); }
         contact_tail(B1, B2, cp1, n1, d1, p1, 1e-3, n, p2, pen, &stable);
@@ -543,6 +554,18 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
 
 }  // namespace
 
+#if DSS_ALL_SHAPES
+namespace dss {
+void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bwd_pre_kernel, dim3(W.B), dim3(64), 0, stream, W, A);
+}
+}  // namespace dss
+#else
+namespace dss {
+void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stream);
+}
+
 extern "C" {
 
 size_t dss_adjoint_sizeof(void) { return sizeof(DssAdjoint); }
@@ -551,7 +574,8 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream_)
 {
     if (!W || !A || !W->tp_pose) return DSS_E_BADARG;
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(bwd_pre_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
+    if (W->shape_rare) dss::launch_bwd_pre_all(*W, *A, stream);
+    else hipLaunchKernelGGL(bwd_pre_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
     int rc = dss_lcp_contact_backward(W->Mblk, W->Je, W->cop, W->cop_body, A->bw_nc, A->bw_active, W->B, W->nb, W->neq,
                                       W->maxc, W->fric_dirs, W->x, W->lam, W->slack, W->nu, A->a_x, A->dMblk, A->dpvec,
                                       A->dcop, nullptr, nullptr, stream_);
@@ -561,3 +585,4 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream_)
 }
 
 }  // extern "C"
+#endif

@@ -60,6 +60,8 @@ def default_vgrad(shape_type, prm, verts):
     Box: only coordinates that ARE +-dims/2 carry a gradient (the reference re-ties the linspace ends),
     d v_k / d dims_k = sign/2.  Sphere: verts = unit * rad, d v / d rad = v / rad."""
     verts = np.asarray(verts, np.float64)
+    if shape_type in (abi.SHAPE_BOX_ROUNDED, abi.SHAPE_BRICK, abi.SHAPE_BOWL):
+        return np.zeros_like(verts)   # level-set / two-parameter meshes: no per-vertex parameter tangent in this layout
     if shape_type == abi.SHAPE_BOX:
         hd = np.asarray(prm, np.float64)[:3] / 2
         return np.where(np.abs(verts) == hd[None, :], 0.5 * np.sign(verts), 0.0)
@@ -107,7 +109,7 @@ class BatchEngine:
     def __init__(self, spec, dt=1.0 / 30, eps=1e-3, tol=1e-8, fric_dirs=8, maxc=64, max_cand=1024, max_pc=32,
                  max_sub=0, strict_no_pen=True, toc_diff=True, lcp_max_iter=10, backend=None):
         """``spec``: numpy arrays pose [B,nb,7], vel [B,nb,6], mass, inertia [B,nb,3,3], restitution, fric,
-        fext [B,nb,6], shape_type, shape_prm [B,nb,3], mesh_id [B,nb], meshes [(verts, faces)...],
+        fext [B,nb,6], shape_type, shape_prm [B,nb,3], shape_aux [B,nb] (optional), mesh_id [B,nb], meshes [(verts, faces)...],
         no_contact [nb,nb] (optional), Je [B,neq,6nb] (optional)."""
         self.be = backend if backend is not None else TorchBackend()
         pose = np.asarray(spec["pose"], np.float64)
@@ -136,6 +138,8 @@ class BatchEngine:
         host.update(pose=pose, vel=spec["vel"], mass=spec["mass"], inertia=np.asarray(spec["inertia"]).reshape(B, nb, 9),
                     restitution=spec["restitution"], fric=spec["fric"], fext=spec["fext"], shape_type=spec["shape_type"],
                     shape_prm=spec["shape_prm"], mesh_id=spec["mesh_id"])
+        if "shape_aux" in spec:
+            host["shape_aux"] = spec["shape_aux"]
         host["no_contact"] = np.asarray(spec.get("no_contact", np.zeros((nb, nb))), np.uint8)
         if neq:
             host["Je"] = Je
@@ -147,6 +151,18 @@ class BatchEngine:
         W.max_cand, W.max_pc, W.nmesh = max_cand, max_pc, len(spec["meshes"])
         W.strict_no_pen, W.toc_diff, W.lcp_max_iter = int(strict_no_pen), int(toc_diff), lcp_max_iter
         W.eps, W.tol, W.dt = eps, tol, dt
+        # Kernel variant (narrowphase.hip, step_bwd.hip): the lean one knows box / sphere / cylinder and thins contact
+        # clusters in LDS; the full one has every primitive and is prepared for level-set meshes (coincident contact
+        # points, clusters of thousands of contacts).  Full when a rare primitive or a dense mesh on a free body exists.
+        full = spec.get("full_kernels")
+        if full is None:
+            full = bool((np.asarray(spec["shape_type"]) > abi.SHAPE_CYLINDER).any())
+            mid = np.asarray(spec["mesh_id"]).reshape(B, nb)
+            for b in range(nb):
+                pinned = neq >= 6 and (np.abs(Je[0][:, 6 * b:6 * b + 6]).sum(axis=1) > 0).sum() >= 6
+                if not pinned and max(len(spec["meshes"][m][1]) for m in set(mid[:, b].tolist())) > 20000:
+                    full = True
+        W.shape_rare = int(bool(full))
         W.max_sub = max_sub
         for name, kind in abi.FIELDS:
             if kind in ("pd", "pi", "pb"):
@@ -168,6 +184,8 @@ class BatchEngine:
         self._set_active(1)
         self._check(L.dss_find_contacts(ctypes.byref(W), self.be.stream()), "dss_find_contacts")
         self._set_active(0)
+        if self.get("overflow").any():
+            self._raise_overflow()
         if strict_no_pen:
             nc = self.get("nc")
             pen = self.get("c_geom")[:, 9, :]
@@ -198,11 +216,21 @@ class BatchEngine:
             self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
                                            ctypes.c_size_t(self.lcp_ws_bytes), self.be.stream()), "dss_step_attempt")
             n = self.be.read_int(self.arr["n_active"])
+            if n & abi.N_ACTIVE_OVERFLOW:
+                self._raise_overflow()
             k += 1
             if k > max_attempts:
                 raise RuntimeError("step did not finish within %d attempts" % max_attempts)
         self.attempts += k
         return k
+
+    def _raise_overflow(self):
+        ov = self.get("overflow")
+        s = int(np.nonzero(ov)[0][0])
+        names = [n for b, n in ((1, "max_cand"), (2, "more than 1024 moving Frank-Wolfe candidates -- or, with the lean kernels (spec['full_kernels'] unset/False), "
+                                         "contacts of one normal cluster -- in a body pair"), (4, "max_pc"), (8, "maxc")) if ov[s] & b]
+        raise RuntimeError("contact detection exceeded a capacity in scene %d (%s): raise the limit when constructing "
+                           "the engine / world -- contacts were dropped, the step is not valid" % (s, ", ".join(names)))
 
     def step_once(self, max_attempts=4096):
         """World.step(fixed_dt=False): a single step_dt -- attempts until the first accepted sub-step
@@ -215,6 +243,8 @@ class BatchEngine:
             self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
                                            ctypes.c_size_t(self.lcp_ws_bytes), self.be.stream()), "dss_step_attempt")
             k += 1
+            if self.get("overflow").any():
+                self._raise_overflow()
             done = self.get("nsub") > before
             a = self.arr["active"]
             a[...] = self.be.from_numpy(np.where(done, 0, self.get("active")).astype(np.int32))

@@ -20,9 +20,10 @@ def _dev(t, dtype=torch.float64):
 
 
 def sdf_query(shape_type, prm, pts, return_grads=True, return_overlapmask=False):
-    """pts [n,3] body-frame points -> sdf [n] (, normalised grad [n,3]) (, overlap mask [n] bool)."""
+    """pts [n,3] body-frame points -> sdf [n] (, normalised grad [n,3]) (, overlap mask [n] bool).
+    prm: up to three shape parameters (+ the corner radius of a rounded box / brick as a fourth entry)."""
     pts = _dev(pts)
-    prm_h = np.zeros(3)
+    prm_h = np.zeros(4)
     p = torch.as_tensor(prm, dtype=torch.float64).detach().cpu().numpy().reshape(-1)
     prm_h[: len(p)] = p
     n = pts.shape[0]

@@ -168,3 +168,45 @@ def marching_cubes_numpy(phi, iso=0.0):
                         f.append(vid[i + c0[0], j + c0[1], k + c0[2], int(e) // 4])
                     faces.append(f)
     return np.array(verts).reshape(-1, 3), np.array(faces, np.int64).reshape(-1, 3)
+
+
+def marching_cubes_numpy_vec(phi, iso=0.0):
+    """`marching_cubes_numpy` with array operations (same vertex / face order); used where a 128^3 grid has to be meshed
+    on the host (golden generation)."""
+    ntri, tri, _ = tables()
+    phi = np.asarray(phi, np.float64)
+    nx, ny, nz = phi.shape
+    inside = phi < iso
+    cut = np.zeros((nx, ny, nz, 3), bool)
+    tpar = np.zeros((nx, ny, nz, 3))
+    for a, sl_lo, sl_hi in ((0, np.s_[:-1, :, :], np.s_[1:, :, :]), (1, np.s_[:, :-1, :], np.s_[:, 1:, :]),
+                            (2, np.s_[:, :, :-1], np.s_[:, :, 1:])):
+        c = inside[sl_lo] != inside[sl_hi]
+        f0, f1 = phi[sl_lo], phi[sl_hi]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(c, (iso - f0) / (f1 - f0), 0.0)
+        cut[sl_lo + (a,)] = c
+        tpar[sl_lo + (a,)] = t
+    vid = np.cumsum(cut.reshape(-1)).reshape(cut.shape) - 1
+    gi, gj, gk, ga = np.nonzero(cut)
+    verts = np.stack([gi, gj, gk], 1).astype(np.float64)
+    verts[np.arange(len(ga)), ga] += tpar[gi, gj, gk, ga]
+    case = np.zeros((nx - 1, ny - 1, nz - 1), np.int64)
+    for c in range(8):
+        case |= inside[(c & 1):nx - 1 + (c & 1), ((c >> 1) & 1):ny - 1 + ((c >> 1) & 1), (c >> 2):nz - 1 + (c >> 2)].astype(np.int64) << c
+    lin = np.arange(case.size).reshape(case.shape)
+    c0 = np.array([edge_corners(e)[0] for e in range(12)], np.int64)
+    faces, keys = [], []
+    for t in range(MAX_TRI):
+        m = ntri[case] > t
+        if not m.any():
+            break
+        ci, cj, ck = np.nonzero(m)
+        e = tri[case[m], t].astype(np.int64)                       # [n, 3] edge ids
+        f = vid[ci[:, None] + c0[e, 0], cj[:, None] + c0[e, 1], ck[:, None] + c0[e, 2], e // 4]
+        faces.append(f)
+        keys.append(lin[m] * MAX_TRI + t)
+    if not faces:
+        return verts.reshape(-1, 3), np.zeros((0, 3), np.int64)
+    faces, keys = np.concatenate(faces), np.concatenate(keys)
+    return verts, faces[np.argsort(keys, kind="stable")].astype(np.int64)

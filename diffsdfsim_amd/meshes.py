@@ -162,3 +162,32 @@ def cylinder_mesh(rad, height, numsegs=32, max_tri_length=0.1):
     vgrad[:len(side), 1] = np.sin(T).reshape(-1)
     vgrad[:, 2] = np.where(verts[:, 2] == hh, 0.5, np.where(verts[:, 2] == -hh, -0.5, 0.0))
     return verts, faces, vgrad
+
+
+def bowl_mesh(r, d, numsegs=32):
+    """Hemispherical shell of mid radius ``r`` and half thickness ``d``, opening towards +z, rim closed by a flat ring
+    (layout of `bodies.py:1029-1065`: inner and outer hemisphere of numsegs/4 latitude rings x numsegs meridians, the pole
+    ring collapsed to one vertex; all vertices lifted by r/2)."""
+    r, d = float(r), float(d)
+    nt = numsegs // 4
+    thetas = _linspace(0.0, -math.pi / 2, nt)
+    phis = _linspace(0.0, 2 * math.pi * (numsegs - 1) / numsegs, numsegs)
+    T, P = np.meshgrid(thetas, phis, indexing="ij")
+
+    def sph(rad):
+        rc = rad * np.cos(T)
+        return np.stack([rc * np.cos(P), rc * np.sin(P), rad * np.sin(T)], axis=0).reshape(3, -1).T
+
+    inds = np.arange(numsegs * nt).reshape(nt, numsegs)
+    n0 = int(inds[-1, 1])                       # keep one vertex of the pole ring
+    v0, v1 = sph(r - d)[:n0], sph(r + d)[:n0]
+    inds[-1] = inds[-1, 0]
+    inds = np.concatenate([inds, inds[:, :1]], axis=1)
+    shell = np.concatenate([np.stack([inds[1:, 1:], inds[:-1, 1:], inds[:-1, :-1]], axis=2).reshape(-1, 3),
+                            np.stack([inds[1:-1, :-1], inds[1:-1, 1:], inds[:-2, :-1]], axis=2).reshape(-1, 3)])
+    rim = np.concatenate([np.stack([inds[0, :-1] + n0, inds[0, 1:] + n0, inds[0, :-1]], axis=1),
+                          np.stack([inds[0, 1:] + n0, inds[0, 1:], inds[0, :-1]], axis=1)])
+    verts = np.concatenate([v0, v1])
+    faces = np.concatenate([shell[:, ::-1], shell + n0, rim]).astype(np.int64)
+    verts[:, 2] += r / 2
+    return verts, faces

@@ -74,8 +74,8 @@ class _PrimitiveMeshSDF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_v, _grad_f):
         verts, p = ctx.saved_tensors
-        out = torch.empty(3, dtype=torch.float64, device=verts.device)
-        prm_h = np.zeros(3); prm_h[: p.numel()] = p.numpy().reshape(-1)
+        out = torch.empty(4, dtype=torch.float64, device=verts.device)
+        prm_h = np.zeros(4); prm_h[: p.numel()] = p.numpy().reshape(-1)
         rc = _lib.lib().dss_meshsdf_backward(int(ctx.shape_type), prm_h.ctypes.data_as(_lib.ctypes.c_void_p), _lib.ptr(verts),
                                              _lib.ptr(grad_v.contiguous()), int(verts.shape[0]), _lib.ptr(out),
                                              _lib.stream_ptr(verts.device))
@@ -85,7 +85,7 @@ class _PrimitiveMeshSDF(torch.autograd.Function):
 
 def primitive_mesh(shape_type, prm_unit, res=128):
     """Unit-frame mesh of an analytic primitive, differentiable w.r.t. its unit parameters (dims/scale; rad/scale;
-    rad/scale, height/scale), as the reference's `self._diff_marching_cubes(self.sdf_func)(*self.params)`."""
+    rad/scale, height/scale; r/scale, d/scale; for a rounded box / brick dims/scale and, fourth, the corner radius/scale), as the reference's `self._diff_marching_cubes(self.sdf_func)(*self.params)`."""
     return _PrimitiveMeshSDF.apply(torch.as_tensor(prm_unit, dtype=torch.float64), int(shape_type), int(res))
 
 

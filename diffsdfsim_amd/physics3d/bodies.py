@@ -83,12 +83,18 @@ class Body3D:
         """`SDF3D.query_sdfs` (sdf_physics/physics3d/bodies.py:721-760) on the device: body-frame points ->
         sdf (, normalised gradient) (, overlap mask).  Values only: the stepper differentiates contact geometry in
         its own backward kernels, not through this query."""
-        return mass_properties.sdf_query(self.shape_type, self.shape_prm(), pts_loc, return_grads, return_overlapmask)
+        prm = torch.cat([self.shape_prm().detach().reshape(-1).to(torch.float64), torch.tensor([self.shape_aux()], dtype=torch.float64)])
+        return mass_properties.sdf_query(self.shape_type, prm, pts_loc, return_grads, return_overlapmask)
+
+    def shape_aux(self):
+        """Constant fourth shape parameter (corner radius of SDFBoxRounded / SDFBrick); 0 for the other bodies."""
+        return 0.0
 
     def _marching_cubes_mesh(self):
         """`SDF3D._create_mesh` (bodies.py:706-711): unit SDF on 128^3 -> marching cubes -> vertices * scale."""
         scale = float(self.scale.detach())
-        v, f = meshsdf.primitive_mesh(self.shape_type, (self.shape_prm().detach() / scale), res=128)
+        unit = torch.cat([self.shape_prm().detach().reshape(-1).to(torch.float64), torch.tensor([self.shape_aux()], dtype=torch.float64)]) / scale
+        v, f = meshsdf.primitive_mesh(self.shape_type, unit, res=128)
         v = (v.detach() * scale).cpu().numpy()
         return v, f.cpu().numpy().astype(np.int64), np.zeros_like(v)
 
@@ -181,3 +187,65 @@ class SDFCylinder(Body3D):
             return self._mesh_ang_inertia(mass)
         a = (3 * self.rad ** 2 + self.height ** 2) / 12
         return mass * torch.diag(torch.stack([a, a, self.rad ** 2 / 2]))
+
+
+class _LevelSetBox(Body3D):
+    """Box-family bodies the reference always meshes with marching cubes and integrates numerically (no custom mesh /
+    inertia options, bodies.py:857-885)."""
+
+    def __init__(self, pos, dims, r, vel=(0, 0, 0, 0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, **kw):
+        self.dims = get_tensor(dims)
+        self.r = get_tensor(r)
+        self.scale = torch.max(self.dims) * 1.5 / 2
+        self.verts_np, self.faces_np, self.vgrad_np = self._marching_cubes_mesh()
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return self.dims
+
+    def shape_aux(self):
+        return float(self.r.detach())
+
+    def _get_ang_inertia(self, mass):
+        return self._mesh_ang_inertia(mass)
+
+
+class SDFBoxRounded(_LevelSetBox):
+    """`sdf_physics/physics3d/bodies.py:857-870`: box of outer size ``dims`` whose edges and corners are rounded with
+    radius ``r`` (box of dims - 2 r, offset by r)."""
+    shape_type = abi.SHAPE_BOX_ROUNDED
+
+
+class SDFBrick(_LevelSetBox):
+    """`sdf_physics/physics3d/bodies.py:873-885`: box whose four edges along z are rounded with radius ``r``."""
+    shape_type = abi.SHAPE_BRICK
+
+
+class SDFBowl(Body3D):
+    """`sdf_physics/physics3d/bodies.py:1013-1065`: hemispherical shell (mid radius ``r``, half thickness ``d``) opening
+    towards the body's +z; inertia from the mesh."""
+    shape_type = abi.SHAPE_BOWL
+
+    def __init__(self, pos, r, d, vel=(0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION, fric_coeff=Defaults3D.FRIC_COEFF,
+                 eps=Defaults3D.EPSILON, custom_mesh=Defaults3D.CUSTOM_MESH, **kw):
+        self.r, self.d = get_tensor(r), get_tensor(d)
+        self.scale = (self.r + self.d) * 1.3333
+        if custom_mesh:
+            v, f = meshes.bowl_mesh(float(self.r.detach()), float(self.d.detach()))
+            self.verts_np, self.faces_np, self.vgrad_np = v, f, np.zeros_like(v)
+        else:
+            self.verts_np, self.faces_np, self.vgrad_np = self._marching_cubes_mesh()
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return torch.stack([self.r.reshape(()), self.d.reshape(()), self.r.new_zeros(())])
+
+    def _get_ang_inertia(self, mass):
+        return self._mesh_ang_inertia(mass)

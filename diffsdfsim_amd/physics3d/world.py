@@ -153,11 +153,17 @@ class World3D(BatchWorld3D):
         spec = dict(pose=npd(st(lambda b: b.p)), vel=npd(st(lambda b: b.v)), mass=npd(P["mass"]), inertia=npd(P["inertia"]),
                     restitution=npd(P["restitution"]), fric=npd(P["fric"]), fext=npd(P["fext"]),
                     shape_type=np.array([[b.shape_type for b in bodies]], np.int32), shape_prm=npd(P["shape_prm"]),
+                    shape_aux=np.array([[b.shape_aux() for b in bodies]], np.float64),
                     mesh_id=np.arange(nb, dtype=np.int32)[None], meshes=[(b.verts_np, b.faces_np) for b in bodies],
                     mesh_vgrad=[b.vgrad_np for b in bodies], Je=Je, no_contact=nocon)
         maxc = 32 * max(1, nb - 1)
+        # level-set meshes (128^3 marching cubes, triangles of ~1/64 of the body's size) put thousands of faces within
+        # eps of a flat neighbour: give the Frank-Wolfe working set room for them
+        pinned = {id(j.body1) for j in constraints if j.J()[0].shape[0] == 6}
+        dense = any(len(b.faces_np) > 20000 and id(b) not in pinned for b in bodies)
         super().__init__(spec, None, dt, eps, tol, fric_dirs, strict_no_penetration, time_of_contact_diff, device,
-                         max_substeps, maxc=maxc)
+                         max_substeps, maxc=4 * maxc if dense else maxc, max_cand=16384 if dense else 1024,
+                         max_pc=128 if dense else 32)
         self.pose = st(lambda b: b.p).to(self.device)      # keep the graph to leaf poses / velocities
         self.vel = st(lambda b: b.v).to(self.device)
         self.eps, self.tol, self.fric_dirs = eps, tol, fric_dirs

@@ -8,18 +8,19 @@ import ctypes
 import numpy as np
 
 CAND_FIELDS = 28
-SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
+N_ACTIVE_OVERFLOW = 1 << 30
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_BOX_ROUNDED, SHAPE_BRICK, SHAPE_BOWL = 0, 1, 2, 3, 4, 5
 
 _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
 # (name, kind) kind: 'i' int scalar, 'd' double scalar, 'pd' double*, 'pi' int*, 'pb' uint8*
 FIELDS = [
     ("B", "i"), ("nb", "i"), ("neq", "i"), ("maxc", "i"), ("fric_dirs", "i"), ("max_cand", "i"), ("max_pc", "i"),
-    ("nmesh", "i"), ("strict_no_pen", "i"), ("toc_diff", "i"), ("lcp_max_iter", "i"),
+    ("nmesh", "i"), ("strict_no_pen", "i"), ("toc_diff", "i"), ("lcp_max_iter", "i"), ("shape_rare", "i"),
     ("eps", "d"), ("tol", "d"), ("dt", "d"),
     ("pose", "pd"), ("vel", "pd"),
     ("mass", "pd"), ("inertia", "pd"), ("restitution", "pd"), ("fric", "pd"), ("fext", "pd"),
-    ("shape_type", "pi"), ("shape_prm", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
+    ("shape_type", "pi"), ("shape_prm", "pd"), ("shape_aux", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
     ("mesh_voff", "pi"), ("mesh_nv", "pi"), ("mesh_foff", "pi"), ("mesh_nf", "pi"),
     ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"), ("vgrad", "pd"),
     ("fch_box", "pd"), ("vch_box", "pd"), ("mesh_fch_off", "pi"), ("mesh_vch_off", "pi"),
@@ -62,7 +63,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
     nz = 6 * nb
     s = {
         "pose": (B, nb, 7), "vel": (B, nb, 6), "mass": (B, nb), "inertia": (B, nb, 9), "restitution": (B, nb),
-        "fric": (B, nb), "fext": (B, nb, 6), "shape_type": (B, nb), "shape_prm": (B, nb, 3), "mesh_id": (B, nb),
+        "fric": (B, nb), "fext": (B, nb, 6), "shape_type": (B, nb), "shape_prm": (B, nb, 3), "shape_aux": (B, nb), "mesh_id": (B, nb),
         "no_contact": (nb, nb), "mesh_voff": (nmesh,), "mesh_nv": (nmesh,), "mesh_foff": (nmesh,), "mesh_nf": (nmesh,),
         "verts": (NV, 3), "faces": (NF, 3), "fcent": (NF, 3), "frad": (NF,), "vgrad": (NV, 3),
         "fch_box": (NFC, 6), "vch_box": (NVC, 6), "mesh_fch_off": (nmesh,), "mesh_vch_off": (nmesh,),

@@ -116,13 +116,17 @@ typedef struct DssWorld {
     int max_cand;   /* Frank-Wolfe working set per directed body pair            */
     int max_pc;     /* contacts kept per directed body pair after filtering      */
     int nmesh, strict_no_pen, toc_diff /* World3D(time_of_contact_diff=...) */, lcp_max_iter;
+    int shape_rare;   /* 0 = lean kernel variants: every shape_type is box / sphere / cylinder and no normal cluster of a
+                         body pair exceeds 1024 contacts (analytic meshes); 1 = full variants (all primitives, level-set
+                         meshes).  See narrowphase.hip. */
     double eps, tol, dt;   /* Defaults3D.EPSILON / TOL (utils.py:45-48), world dt */
     /* body state [B][nb][7] / [B][nb][6] */
     double *pose, *vel;
     /* body parameters, [B][nb](...) */
     const double *mass, *inertia /*[9]*/, *restitution, *fric, *fext /*[6]*/;
     const int *shape_type;      /* DSS_SHAPE_* */
-    const double *shape_prm;    /* [3]: box dims | sphere radius | cylinder rad, height */
+    const double *shape_prm;    /* [3]: box, rounded box, brick dims | sphere radius | cylinder rad, height | bowl r, d */
+    const double *shape_aux;    /* [B][nb]: corner radius r of a rounded box / brick (a constant, not differentiated) */
     const int *mesh_id;
     const unsigned char *no_contact; /* [nb][nb], shared by all scenes */
     /* mesh table (body frame) */
@@ -145,7 +149,7 @@ typedef struct DssWorld {
     int *active;     /* 1 while t < t_end in the current outer step */
     int *toc;        /* reference's `toc_contacts` non-empty */
     int *nsub;       /* accepted sub-steps so far (tape slot) */
-    int *n_active;   /* [1] number of scenes still active after dss_step_decide */
+    int *n_active;   /* [1] number of scenes still active after dss_step_decide | DSS_N_ACTIVE_OVERFLOW */
     /* current contacts (geometry at the current pose) [B][...] */
     int *nc;                 /* [B] */
     int *c_body;             /* [B][2][maxc] */
@@ -167,7 +171,7 @@ typedef struct DssWorld {
     int *n_pairs;            /* [6]: workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
                                 work cursors, deferred-list length and cursor */
     int *invalid;            /* [B] penetration > tol found in this attempt */
-    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 cluster>1024, 4 max_pc, 8 maxc */
+    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc */
     int *pc_count;           /* [B][npairs] */
     int *pc_stats;           /* [B][npairs][2] work done for the pair: face runs tested, candidate faces (bench accounting) */
     int *pc_face;            /* [B][npairs][max_pc] */
@@ -188,11 +192,15 @@ typedef struct DssWorld {
     long long *dbg_stamps;
 } DssWorld;
 
+#define DSS_N_ACTIVE_OVERFLOW (1 << 30)   /* set in n_active[0] once any scene's overflow word is non-zero */
 #define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */
 #define DSS_CSCR_ROWS 56
 #define DSS_SHAPE_BOX 0
 #define DSS_SHAPE_SPHERE 1
 #define DSS_SHAPE_CYLINDER 2   /* shape_prm = (rad, height, -), axis = body z */
+#define DSS_SHAPE_BOX_ROUNDED 3 /* SDFBoxRounded (bodies.py:857-870): shape_prm = outer dims, shape_aux = r */
+#define DSS_SHAPE_BRICK 4      /* SDFBrick (bodies.py:873-885): shape_prm = dims, shape_aux = r (x-y corners rounded) */
+#define DSS_SHAPE_BOWL 5       /* SDFBowl (bodies.py:1013-1027): shape_prm = (r, d, -), opening towards +z */
 
 size_t dss_world_sizeof(void);
 /* scratch slots the narrow phase needs for a batch of B scenes with nb bodies (sizes cand_face/cand_state/cand_buf) */
@@ -260,8 +268,9 @@ int dss_igr_query_latent_grad(const double *pts, const double *latent, const dou
  * World-construction side of the path
  *
  * dss_sdf_query replaces SDF3D.query_sdfs (sdf_physics/physics3d/bodies.py:721-760) for the analytic primitives:
- *   pts [n][3] in the body frame (world units), prm = shape parameters in world units (box: dims; sphere: rad;
- *   cylinder: rad, height) -> sdf [n], grad [n][3] (normalised; may be NULL = return_grads False),
+ *   pts [n][3] in the body frame (world units), prm [4] (host) = shape parameters in world units (box, rounded box,
+ *   brick: dims; sphere: rad; cylinder: rad, height; bowl: r, d) and, fourth, the corner radius of a rounded box / brick
+ *   (bodies.py:38-185, 778-1027) -> sdf [n], grad [n][3] (normalised; may be NULL = return_grads False),
  *   overlap_mask [n] (1 inside the [-scale, scale]^3 query cube; may be NULL).  Outside the cube sdf = scale, grad = 0.
  * dss_mesh_inertia replaces get_ang_inertia (bodies.py:260-395) for a pooled table of closed triangle meshes
  *   (same table layout as DssWorld: verts [NV][3], faces [NF][3] mesh-local indices, mesh_voff/foff/nf [nmesh]):
@@ -289,8 +298,9 @@ int dss_selftest_sqrt(const double *x, int n, int *mismatches, void *stream);
  *   dss_mc_count  -> totals[0] = vertices, totals[1] = triangles (device ints; read them, allocate, then)
  *   dss_mc_emit   -> verts [V][3] in grid-index units (the caller maps to [-1,1]: v/(res-1)*2-1), faces [F][3].
  *   The workspace passed to dss_mc_emit must be the one dss_mc_count filled.
- *   dss_meshsdf_backward: grad_prm[3] = sum_v -(grad_verts[v] . n_v) d phi / d unit_prm (v), analytic primitives,
- *   unit frame of the reference (params already divided by the body scale, vertices in [-1,1]^3). */
+ *   dss_meshsdf_backward: grad_prm[4] = sum_v -(grad_verts[v] . n_v) d phi / d unit_prm (v), analytic primitives,
+ *   unit frame of the reference (unit_prm [4] host = the three parameters and the corner radius, already divided by the
+ *   body scale; vertices in [-1,1]^3). */
 size_t dss_mc_workspace_bytes(int n0, int n1, int n2);
 int dss_mc_count(const double *phi, int n0, int n1, int n2, double iso, const int *ntri_tab, void *workspace,
                  size_t workspace_bytes, int *totals, void *stream);

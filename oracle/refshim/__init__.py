@@ -8,7 +8,7 @@ into ``sys.modules``:
 
 * *functional* stand-ins restate the documented arithmetic of the symbols the physics
   path really calls (``pytorch3d.transforms`` quaternion / SO(3) helpers, the ODE
-  broadphase callback loop, ``trimesh.creation.icosphere``);
+  broadphase callback loop, ``trimesh.creation.icosphere``, ``ev_sdf_utils.marching_cubes / grid_interp``);
 * *inert* stand-ins only satisfy ``import`` (render / plotting / alternative solver).
 
 Nothing here is imported by the product (``diffsdfsim_amd``); it is used by
@@ -57,7 +57,7 @@ def install(device="cpu"):
     if not os.path.isdir(REFERENCE_ROOT):
         raise RuntimeError("reference tree not present at %s (goldens can only be generated "
                            "in the build container)" % REFERENCE_ROOT)
-    from . import fake_ode, fake_pytorch3d, fake_trimesh
+    from . import fake_ev_sdf_utils, fake_ode, fake_pytorch3d, fake_trimesh
 
     sys.modules.setdefault("ode", fake_ode)
     p3d = types.ModuleType("pytorch3d")
@@ -69,7 +69,8 @@ def install(device="cpu"):
     sys.modules.setdefault("pytorch3d.loss", loss)
     sys.modules.setdefault("trimesh", fake_trimesh)
     sys.modules.setdefault("trimesh.creation", fake_trimesh.creation)
-    for name in ("pygame", "cvxpy", "pyrender", "pyhocon", "ev_sdf_utils"):
+    sys.modules.setdefault("ev_sdf_utils", fake_ev_sdf_utils)
+    for name in ("pygame", "cvxpy", "pyrender", "pyhocon"):
         sys.modules.setdefault(name, _inert(name))
     os.environ.setdefault("IGR_PATH", "/tmp")
     os.environ.setdefault("PYOPENGL_PLATFORM", "egl")

@@ -1,0 +1,33 @@
+"""Functional stand-in for ``ev_sdf_utils`` (un-vendored CUDA extension), golden generation only.
+
+``marching_cubes(sdfs, iso)``: level-set mesh in grid-index units.  The extension's vertex / face order is
+implementation-defined; this stand-in uses the build's own generated case tables (diffsdfsim_amd/mc_tables.py, numpy), so
+that the reference and the build simulate the SAME mesh and their trajectories can be compared.
+``grid_interp(grid, inds)``: trilinear interpolation of grid [n0,n1,n2] (or channel-first [C,n0,n1,n2]) at fractional
+index positions inds [N,3] -> [N] (or [N,C]); the documented meaning of the call sites at
+`sdf_physics/physics3d/bodies.py:203-241`.
+"""
+import numpy as np
+import torch
+
+from diffsdfsim_amd import mc_tables
+
+
+def marching_cubes(sdfs, iso):
+    v, f = mc_tables.marching_cubes_numpy_vec(sdfs.detach().cpu().numpy(), float(iso))
+    return torch.tensor(v, dtype=sdfs.dtype), torch.tensor(f, dtype=torch.int64)
+
+
+def grid_interp(grid, inds):
+    chan = grid.dim() == 4
+    g = grid if chan else grid.unsqueeze(0)
+    n = torch.tensor(g.shape[1:], dtype=torch.long)
+    i0 = torch.minimum(torch.clamp(inds.floor().long(), min=0), n - 2)
+    w = inds - i0.to(inds.dtype)
+    out = 0
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                wt = (w[:, 0] if dx else 1 - w[:, 0]) * (w[:, 1] if dy else 1 - w[:, 1]) * (w[:, 2] if dz else 1 - w[:, 2])
+                out = out + g[:, i0[:, 0] + dx, i0[:, 1] + dy, i0[:, 2] + dz] * wt
+    return out.t() if chan else out[0]

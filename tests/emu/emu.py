@@ -138,7 +138,7 @@ def igr_query(pts, latent, Ws, bs, wrt="xyz"):
 def sdf_query(shape_type, prm, pts):
     L = lib()
     pts = _c(pts); n = len(pts)
-    prm = _c(np.concatenate([np.asarray(prm, np.float64).reshape(-1), np.zeros(3)])[:3])
+    prm = _c(np.concatenate([np.asarray(prm, np.float64).reshape(-1), np.zeros(4)])[:4])
     sdf = np.zeros(n); grad = np.zeros((n, 3)); mask = np.zeros(n, np.uint8)
     rc = L.dss_sdf_query(int(shape_type), _p(prm), _p(pts), n, _p(sdf), _p(grad), _p(mask), None)
     assert rc == 0
@@ -176,11 +176,12 @@ def marching_cubes(phi, iso=0.0):
 
 def meshsdf_backward(shape_type, unit_prm, unit_verts, gbar):
     L = lib()
-    prm = _c(np.concatenate([np.asarray(unit_prm, np.float64).reshape(-1), np.zeros(3)])[:3])
-    V = _c(unit_verts); Gb = _c(gbar); out = np.zeros(3)
+    k = np.asarray(unit_prm).size
+    prm = _c(np.concatenate([np.asarray(unit_prm, np.float64).reshape(-1), np.zeros(4)])[:4])
+    V = _c(unit_verts); Gb = _c(gbar); out = np.zeros(4)
     rc = L.dss_meshsdf_backward(int(shape_type), _p(prm), _p(V), _p(Gb), len(V), _p(out), None)
     assert rc == 0
-    return out
+    return out[:max(k, 3)]
 
 
 def mesh_inertia_backward(verts, faces, mass, gJ):

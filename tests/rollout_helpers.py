@@ -10,15 +10,17 @@ def load_rollout(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
-def spec_from_golden(g, copies=1):
-    """Scene replicated `copies` times along the batch axis (identical scenes must give identical results)."""
+def spec_from_golden(g, copies=1, level_set_mesh=None):
+    """Scene replicated `copies` times along the batch axis (identical scenes must give identical results).
+    Bodies whose (level-set) mesh is not in the golden get it from `level_set_mesh(body index)`."""
     nb = len(g["mass"])
-    meshes = [(g["verts_%d" % i], g["faces_%d" % i]) for i in range(nb)]
+    meshes = [(g["verts_%d" % i], g["faces_%d" % i]) if "verts_%d" % i in g else level_set_mesh(i) for i in range(nb)]
     rep = lambda a: np.repeat(np.asarray(a)[None], copies, axis=0)
     Je = np.zeros((6 * len(g["fixed"]), 6 * nb))
     for k, b in enumerate(g["fixed"]):
         Je[6 * k:6 * k + 6, 6 * b:6 * b + 6] = np.eye(6)   # TotalConstraint3D.J() = I_6 (constraints.py:131-137)
-    return dict(pose=rep(g["pose0"]), vel=rep(g["vel0"]), mass=rep(g["mass"]), inertia=rep(g["inertia"]),
+    extra = dict(shape_aux=rep(g["shape_aux"])) if "shape_aux" in g else {}
+    return dict(extra, pose=rep(g["pose0"]), vel=rep(g["vel0"]), mass=rep(g["mass"]), inertia=rep(g["inertia"]),
                 restitution=rep(g["restitution"]), fric=rep(g["fric"]), fext=rep(g["fext"]),
                 shape_type=rep(g["shape_type"]), shape_prm=rep(g["shape_prm"]), mesh_id=rep(np.arange(nb)),
                 meshes=meshes, Je=rep(Je))

@@ -8,10 +8,10 @@ import pytest
 from emu import emu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
-TYPES = {"box": 0, "sphere": 1, "cylinder": 2}
+TYPES = {"box": 0, "sphere": 1, "cylinder": 2, "rounded": 3, "brick": 4, "bowl": 5}
 
 
-@pytest.mark.parametrize("name", ["box", "sphere", "cylinder"])
+@pytest.mark.parametrize("name", ["box", "sphere", "cylinder", "rounded", "brick", "bowl"])
 def test_query_sdfs_matches_reference(name):
     g = np.load(os.path.join(G, "sdf_query.npz"))
     sdf, grad, mask = emu.sdf_query(TYPES[name], g[name + "_prm"], g[name + "_pts"])

@@ -9,10 +9,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
-TYPES = {"box": 0, "sphere": 1, "cylinder": 2}
+TYPES = {"box": 0, "sphere": 1, "cylinder": 2, "rounded": 3, "brick": 4, "bowl": 5}
 
 
-@pytest.mark.parametrize("name", ["box", "sphere", "cylinder"])
+@pytest.mark.parametrize("name", ["box", "sphere", "cylinder", "rounded", "brick", "bowl"])
 def test_query_sdfs_matches_reference(name):
     from diffsdfsim_amd.mass_properties import sdf_query
     g = np.load(os.path.join(G, "sdf_query.npz"))
