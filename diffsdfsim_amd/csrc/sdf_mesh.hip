@@ -33,6 +33,56 @@ __global__ void __launch_bounds__(256) sdf_query_kernel(int type, double p0, dou
     if (mask) mask[i] = in ? 1 : 0;
 }
 
+// SDFGrid3D.query_sdfs (bodies.py:203-241, 721-775): the body's SDF is a voxel grid over its unit cube.  Value: trilinear
+// interpolation at inds = (p + 1) / 2 * (n - 1); gradient: the central-difference field (zero in the boundary layers) of
+// the grid, interpolated the same way, normalised (grid_sdf_grad) and normalised again (query_sdfs).  The interpolation
+// itself is `ev_sdf_utils.grid_interp`, un-vendored: trilinear with the cell index clamped to [0, n - 2].
+__global__ void __launch_bounds__(256) grid_sdf_query_kernel(const double *__restrict__ G, int n0, int n1, int n2, double scale,
+                                                            const double *pts, int n, double *sdf, double *grad, unsigned char *mask)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const double pt[3] = {pts[3 * (size_t)t], pts[3 * (size_t)t + 1], pts[3 * (size_t)t + 2]};
+    const bool in = fabs(pt[0]) <= scale && fabs(pt[1]) <= scale && fabs(pt[2]) <= scale;
+    if (mask) mask[t] = in ? 1 : 0;
+    if (!in) {
+        sdf[t] = scale;
+        if (grad) { grad[3 * (size_t)t] = 0.0; grad[3 * (size_t)t + 1] = 0.0; grad[3 * (size_t)t + 2] = 0.0; }
+        return;
+    }
+    const int nn[3] = {n0, n1, n2};
+    int i0[3];
+    double w[3];
+    for (int d = 0; d < 3; ++d) {
+        const double ind = (pt[d] / scale + 1.0) * 0.5 * (double)(nn[d] - 1);
+        int c = (int)floor(ind);
+        c = c < 0 ? 0 : (c > nn[d] - 2 ? nn[d] - 2 : c);
+        i0[d] = c; w[d] = ind - (double)c;
+    }
+    auto at = [&](int i, int j, int k) { return G[((size_t)i * n1 + j) * n2 + k]; };
+    double phi = 0.0, g[3] = {0.0, 0.0, 0.0};
+    for (int dx = 0; dx < 2; ++dx)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dz = 0; dz < 2; ++dz) {
+                const double wt = (dx ? w[0] : 1.0 - w[0]) * (dy ? w[1] : 1.0 - w[1]) * (dz ? w[2] : 1.0 - w[2]);
+                const int i = i0[0] + dx, j = i0[1] + dy, k = i0[2] + dz;
+                phi = phi + at(i, j, k) * wt;
+                if (grad) {
+                    const double cx = (i == 0 || i == n0 - 1) ? 0.0 : (at(i + 1, j, k) - at(i - 1, j, k)) / 2.0;
+                    const double cy = (j == 0 || j == n1 - 1) ? 0.0 : (at(i, j + 1, k) - at(i, j - 1, k)) / 2.0;
+                    const double cz = (k == 0 || k == n2 - 1) ? 0.0 : (at(i, j, k + 1) - at(i, j, k - 1)) / 2.0;
+                    g[0] = g[0] + cx * wt; g[1] = g[1] + cy * wt; g[2] = g[2] + cz * wt;
+                }
+            }
+    sdf[t] = phi * scale;
+    if (grad) {
+        double g1[3], g2[3];
+        normalize(g, g1);
+        normalize(g1, g2);
+        grad[3 * (size_t)t] = g2[0]; grad[3 * (size_t)t + 1] = g2[1]; grad[3 * (size_t)t + 2] = g2[2];
+    }
+}
+
 // The ten volume-integral contributions of one face (comp_projection_integrals / comp_face_integrals /
 // comp_volume_integrals, bodies.py:260-377): c[0] -> T0, c[1..3] -> 2 T1, c[4..6] -> 3 T2, c[7..9] -> 2 TP.
 // Templated on the scalar so that the backward differentiates the same code with dual numbers.
@@ -229,6 +279,15 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
     if (shape_type < DSS_SHAPE_BOX || shape_type > DSS_SHAPE_BOWL) return DSS_E_UNSUPPORTED;
     hipLaunchKernelGGL(sdf_query_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shape_type, prm[0], prm[1],
                        prm[2], prm[3], pts, n, sdf, grad, overlap_mask);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+
+int dss_grid_sdf_query(const double *grid, int n0, int n1, int n2, double scale, const double *pts, int n, double *sdf,
+                       double *grad, unsigned char *overlap_mask, void *stream)
+{
+    if (!grid || !pts || !sdf || n <= 0 || n0 < 2 || n1 < 2 || n2 < 2 || !(scale > 0.0)) return DSS_E_BADARG;
+    hipLaunchKernelGGL(grid_sdf_query_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, grid, n0, n1, n2, scale, pts,
+                       n, sdf, grad, overlap_mask);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 

@@ -39,6 +39,23 @@ def sdf_query(shape_type, prm, pts, return_grads=True, return_overlapmask=False)
     return out if len(out) > 1 else out[0]
 
 
+def grid_sdf_query(grid, scale, pts, return_grads=True, return_overlapmask=False):
+    """`SDF3D.query_sdfs` of an SDFGrid3D body (bodies.py:203-241, 763-775): grid [n0,n1,n2] over the unit cube."""
+    pts, grid = _dev(pts), _dev(grid)
+    n = pts.shape[0]
+    sdf = torch.empty(n, dtype=torch.float64, device=pts.device)
+    grad = torch.empty(n, 3, dtype=torch.float64, device=pts.device) if return_grads else None
+    mask = torch.empty(n, dtype=torch.uint8, device=pts.device) if return_overlapmask else None
+    if n:
+        rc = _lib.lib().dss_grid_sdf_query(_lib.ptr(grid), int(grid.shape[0]), int(grid.shape[1]), int(grid.shape[2]),
+                                           _lib.ctypes.c_double(float(scale)), _lib.ptr(pts), int(n), _lib.ptr(sdf),
+                                           _lib.ptr(grad) if return_grads else None,
+                                           _lib.ptr(mask) if return_overlapmask else None, _lib.stream_ptr(pts.device))
+        _lib.check(rc, "dss_grid_sdf_query")
+    out = (sdf,) + ((grad,) if return_grads else ()) + ((mask.bool(),) if return_overlapmask else ())
+    return out if len(out) > 1 else out[0]
+
+
 def mesh_inertia(verts, faces, mass, return_volume=False):
     """One closed triangle mesh (verts [V,3], faces [F,3]) or a list of them -> inertia tensor(s) [3,3] about the
     mesh origin for the given mass(es) at uniform density."""

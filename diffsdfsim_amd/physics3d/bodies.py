@@ -249,3 +249,34 @@ class SDFBowl(Body3D):
 
     def _get_ang_inertia(self, mass):
         return self._mesh_ang_inertia(mass)
+
+
+class SDFGrid3D(Body3D):
+    """`sdf_physics/physics3d/bodies.py:763-775`: the SDF is a voxel grid ``sdf`` [n,n,n] over the body's unit cube
+    (``scale`` maps it to world units).  Mesh: marching cubes of the grid itself at its own resolution; inertia from
+    the mesh; queries through dss_grid_sdf_query.  A grid body can be built, meshed and queried; the batched stepper
+    does not take grid bodies yet (World3D raises)."""
+    shape_type = None
+
+    def __init__(self, pos, scale, sdf, vel=(0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
+                 fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, **kw):
+        self.scale = get_tensor(scale)
+        self.sdf = torch.as_tensor(sdf, dtype=torch.float64)
+        res = self.sdf.shape[0]
+        v, f = meshsdf.marching_cubes(self.sdf, 0.0)
+        v = (v / (res - 1) * 2.0 - 1.0) * float(self.scale.detach())
+        self.verts_np, self.faces_np = v.cpu().numpy(), f.cpu().numpy().astype(np.int64)
+        self.vgrad_np = np.zeros_like(self.verts_np)
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        raise NotImplementedError("SDFGrid3D bodies are not part of the batched stepper yet")
+
+    def query_sdfs(self, pts_loc, return_grads=True, return_overlapmask=False):
+        return mass_properties.grid_sdf_query(self.sdf, float(self.scale.detach()), pts_loc, return_grads, return_overlapmask)
+
+    def _get_ang_inertia(self, mass):
+        return self._mesh_ang_inertia(mass)

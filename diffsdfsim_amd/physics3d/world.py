@@ -130,6 +130,8 @@ class World3D(BatchWorld3D):
         self.engine_plugin = engine() if isinstance(engine, type) else getattr(engines_module, engine)()
         self.bodies = bodies
         self.vec_len = 6
+        if any(b.shape_type is None for b in bodies):
+            raise NotImplementedError("SDFGrid3D bodies can be built, meshed and queried, but are not in the batched stepper yet")
         nb = len(bodies)
         idx = {id(b): i for i, b in enumerate(bodies)}
         rows = []

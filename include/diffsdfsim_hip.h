@@ -280,6 +280,11 @@ int dss_sdf_query(int shape_type, const double *prm, const double *pts, int n, d
                   unsigned char *overlap_mask, void *stream);
 int dss_mesh_inertia(const double *verts, const int *faces, const int *mesh_voff, const int *mesh_foff, const int *mesh_nf,
                      int nmesh, const double *mass, double *J, double *volume, void *stream);
+/* The same query for SDFGrid3D (bodies.py:203-241, 763-775): grid [n0][n1][n2] (device) = SDF samples over the body's unit
+ * cube, scale = the body's scale.  Value by trilinear interpolation, gradient from the interpolated central-difference
+ * field, normalised.  (`grid_interp` of the un-vendored ev_sdf_utils is restated as plain trilinear interpolation.) */
+int dss_grid_sdf_query(const double *grid, int n0, int n1, int n2, double scale, const double *pts, int n, double *sdf,
+                       double *grad, unsigned char *overlap_mask, void *stream);
 
 /* Adjoint of dss_mesh_inertia for ONE mesh: grad_verts [nv][3] = d (sum_ab grad_J[a][b] J[a][b]) / d verts
  * (the reference differentiates get_ang_inertia with autograd, bodies.py:380-395). */

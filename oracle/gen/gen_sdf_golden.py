@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 from oracle import refshim  # noqa: E402
 
 refshim.install()
-from sdf_physics.physics3d.bodies import (SDFBowl, SDFBox, SDFBoxRounded, SDFBrick, SDFCylinder, SDFSphere,  # noqa: E402
-                                          get_ang_inertia)
+from sdf_physics.physics3d.bodies import (SDFBowl, SDFBox, SDFBoxRounded, SDFBrick, SDFCylinder, SDFGrid3D,  # noqa: E402
+                                          SDFSphere, get_ang_inertia)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -70,6 +70,21 @@ def main():
         inert[name + "_verts"] = v.numpy(); inert[name + "_faces"] = f.numpy().astype(np.int32)
         inert[name + "_J"] = J.numpy(); inert[name + "_mass"] = 2.5
         print(name, "scale", scale, "n", len(pts), "inside cube", int(mask.sum()), "J diag", np.diag(J.numpy()))
+    # SDFGrid3D (bodies.py:763-775): an ellipsoid-like level set sampled on 24^3.  grid_interp comes from the stand-in
+    # (plain trilinear interpolation), so this vector pins the index mapping, the central-difference field, the masks and
+    # the normalisations of the reference's grid_sdf / grid_sdf_grad / query_sdfs around it.
+    n = 24
+    lin = np.linspace(-1.0, 1.0, n)
+    X, Y, Z = np.meshgrid(lin, lin, lin, indexing="ij")
+    grid = np.sqrt((X / 0.8) ** 2 + (Y / 0.6) ** 2 + (Z / 0.7) ** 2) - 1.0 + 0.05 * np.sin(3 * X) * np.cos(2 * Y)
+    body = SDFGrid3D([0, 0, 0], 0.9, torch.tensor(grid))
+    r = np.random.default_rng(77)
+    pts = np.concatenate([r.uniform(-1.1 * 0.9, 1.1 * 0.9, (200, 3)), np.array([[0.9, 0.9, 0.9], [-0.9, 0.0, 0.0], [0.0, 0.0, 0.0]]),
+                          0.9 * np.stack([lin[[0, 5, 23, 11]], lin[[3, 0, 23, 12]], lin[[7, 23, 0, 12]]], 1)])
+    sdf, grad, mask = body.query_sdfs(torch.tensor(pts), return_grads=True, return_overlapmask=True)
+    out.update(grid_grid=grid, grid_scale=0.9, grid_pts=pts, grid_sdf=sdf.detach().numpy(), grid_grad=grad.detach().numpy(),
+               grid_mask=mask.numpy())
+    print("grid", "inside cube", int(mask.sum()), "mesh", tuple(body.verts.shape), tuple(body.faces.shape))
     np.savez_compressed(os.path.join(OUT, "sdf_query.npz"), **out)
     np.savez_compressed(os.path.join(OUT, "mesh_inertia.npz"), **inert)
 

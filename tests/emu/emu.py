@@ -145,6 +145,16 @@ def sdf_query(shape_type, prm, pts):
     return sdf, grad, mask.astype(bool)
 
 
+def grid_sdf_query(grid, scale, pts):
+    L = lib()
+    G = _c(grid); pts = _c(pts); n = len(pts)
+    sdf = np.zeros(n); grad = np.zeros((n, 3)); mask = np.zeros(n, np.uint8)
+    rc = L.dss_grid_sdf_query(_p(G), G.shape[0], G.shape[1], G.shape[2], ctypes.c_double(scale), _p(pts), n, _p(sdf), _p(grad),
+                              _p(mask), None)
+    assert rc == 0
+    return sdf, grad, mask.astype(bool)
+
+
 def mesh_inertia(verts, faces, mass):
     L = lib()
     V = _c(verts); F = _c(faces, np.int32)

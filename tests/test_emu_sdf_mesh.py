@@ -43,3 +43,12 @@ def test_mesh_inertia_backward_matches_finite_differences():
         vp[i, d] += h; vm[i, d] -= h
         fd = ((emu.mesh_inertia(vp, f, 1.7)[0] - emu.mesh_inertia(vm, f, 1.7)[0]) * gJ).sum() / (2 * h)
         assert abs(g[i, d] - fd) < 1e-6 * max(1.0, abs(fd)), (i, d, g[i, d], fd)
+
+
+def test_grid_sdf_query_matches_reference():
+    """SDFGrid3D.query_sdfs (bodies.py:203-241, 763-775) recorded from the reference with trilinear `grid_interp`."""
+    g = np.load(os.path.join(G, "sdf_query.npz"))
+    sdf, grad, mask = emu.grid_sdf_query(g["grid_grid"], float(g["grid_scale"]), g["grid_pts"])
+    assert np.array_equal(mask, g["grid_mask"])
+    assert np.abs(sdf - g["grid_sdf"]).max() < 1e-14
+    assert np.abs(grad - g["grid_grad"]).max() < 1e-12

@@ -88,3 +88,22 @@ def test_unscaled_square_root_is_bit_identical_to_sqrt():
     bad = torch.zeros(1, dtype=torch.int32, device="cuda")
     _lib.check(_lib.lib().dss_selftest_sqrt(_lib.ptr(tx), n, _lib.ptr(bad), _lib.stream_ptr(tx.device)), "dss_selftest_sqrt")
     assert int(bad.item()) == 0
+
+
+def test_grid_body_queries_mesh_and_inertia():
+    """SDFGrid3D (bodies.py:763-775): queries against the reference's vector, mesh = level set of the grid (closed,
+    vertices on the zero set of the interpolant), inertia from that mesh."""
+    from diffsdfsim_amd.physics3d import SDFGrid3D
+    g = np.load(os.path.join(G, "sdf_query.npz"))
+    b = SDFGrid3D([0, 0, 0], float(g["grid_scale"]), g["grid_grid"], mass=2.0)
+    sdf, grad, mask = b.query_sdfs(torch.as_tensor(g["grid_pts"]), True, True)
+    assert np.array_equal(mask.cpu().numpy(), g["grid_mask"])
+    assert np.abs(sdf.cpu().numpy() - g["grid_sdf"]).max() < 1e-14 and np.abs(grad.cpu().numpy() - g["grid_grad"]).max() < 1e-12
+    on_surface = b.query_sdfs(b.verts, return_grads=False)
+    assert float(on_surface.abs().max()) < 1e-12           # marching-cubes vertices lie on grid edges: the interpolant is linear there
+    f = b.faces.numpy()
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all()                                  # closed manifold
+    J = b.ang_inertia.numpy()
+    assert np.allclose(J, J.T, atol=1e-12) and (np.linalg.eigvalsh(J) > 0).all()
