@@ -1,0 +1,97 @@
+"""CPU, build container only: boundary B1 exercised by the REFERENCE's own code.
+
+BASELINE.json configs[0] is the reference's CPU case: lcp_physics' 2-D world (Circle bouncing on a Rect, analytic
+contacts, `lcp_physics/physics/world.py`, `engines.py:31-83`), 50 steps forward + backward.  Here that world runs
+unmodified, with one substitution: `engine.lcp_solver`, the `LCPFunction` it instantiates at engines.py:81, is replaced by
+an autograd Function whose forward / backward are this build's dense LCP kernels (csrc/lcp_dense.hip) -- compiled for the
+test-only CPU emulator, since the reference and a GPU never exist on the same machine.  Final state, loss and
+d loss / d radius must equal what the reference produced with its own solver (tests/golden/config1_lcp.npz).
+Skipped where /root/reference is absent (the GPU box); the same kernels run there through
+test_lcp_dense_gpu.py::test_config1_reference_cpu_case_through_lcpfunction on the recorded operands."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emu import emu
+from helpers import GOLDEN
+
+REF = os.environ.get("DIFFSDFSIM_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+
+
+def kernel_lcp_function(calls):
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, Q, p, G, h, A, b, F, max_iter):
+            neq = A.shape[1] if A.numel() else 0
+            ops = [t.detach().numpy() for t in (Q, p, G, h)] + [A.detach().numpy() if neq else np.zeros((1, 0, Q.shape[1])),
+                                                                  b.detach().numpy() if neq else np.zeros((1, 0)), F.detach().numpy()]
+            z, lam, s, nu, it, st = emu.lcp_dense_forward(*ops, max_iter=max_iter)
+            ctx.ops, ctx.sol, ctx.neq = ops, (z, lam, s, nu), neq
+            calls.append(int(it[0]))
+            return torch.as_tensor(z)
+
+        @staticmethod
+        def backward(ctx, dl):
+            Q, p, G, h, A, b, F = ctx.ops
+            z, lam, s, nu = ctx.sol
+            dQ, dp, dG, dh, dA, db, dF = emu.lcp_dense_backward(Q, G, A, F, z, lam, s, nu, dl.numpy())
+            t = torch.as_tensor
+            return t(dQ), t(dp), t(dG), t(dh), (t(dA) if ctx.neq else None), (t(db) if ctx.neq else None), t(dF), None
+
+    def LCPFunction(max_iter=20, **_kw):      # the constructor signature of lcp.py:43-46, as engines.py:81 calls it
+        return lambda Q, p, G, h, A, b, F: Fn.apply(Q, p, G, h, A, b, F, max_iter)
+    return LCPFunction
+
+
+def test_reference_2d_world_on_the_builds_lcp_kernels():
+    from oracle import refshim
+    refshim.install()
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import TotalConstraint
+    from lcp_physics.physics.forces import Gravity
+    from lcp_physics.physics.world import World
+
+    g = np.load(os.path.join(GOLDEN, "config1_lcp.npz"))
+    rad = torch.tensor(20.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.5, fric_coeff=0.9)
+    ball = Circle([500, 480], rad, vel=[0, 30, 0], restitution=0.5, fric_coeff=0.9)
+    ball.add_force(Gravity(g=100))
+    calls = []
+    w = World([floor, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+    w.engine.lcp_solver = kernel_lcp_function(calls)
+    for _ in range(50):
+        w.step()
+    loss = (ball.pos ** 2).sum()
+    loss.backward()
+    assert len(calls) == int(g["n_calls"]) and len(w.trajectory) == int(g["n_substeps"])
+    final_p = torch.cat([b.p for b in (floor, ball)]).detach().numpy()
+    assert np.abs(final_p - g["final_p"]).max() < 1e-8 * np.abs(g["final_p"]).max()
+    assert abs(float(loss) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
+    assert abs(float(rad.grad) - float(g["drad"])) < 1e-6 * abs(float(g["drad"])), (float(rad.grad), float(g["drad"]))
+
+
+def test_reference_3d_world_on_the_builds_lcp_kernels():
+    """The same substitution under the reference's World3D (FWContactHandler, PdipmEngine): config 2's scene, one sphere
+    dropped on the floor, 24 steps with time-of-contact differentials, against the rollout recorded with the
+    reference's own solver (tests/golden/rollout_sphere.npz): trajectory and d sum|pos|^2 / d radius."""
+    from oracle import refshim
+    refshim.install()
+    from oracle.gen import scenes
+    from sdf_physics.physics3d.world import World3D
+
+    g = np.load(os.path.join(GOLDEN, "rollout_sphere.npz"))
+    bodies, joints, params = scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0))
+    calls = []
+    w = World3D(bodies, joints, time_of_contact_diff=True)
+    w.engine.lcp_solver = kernel_lcp_function(calls)
+    for _ in range(24):
+        w.step(fixed_dt=True)
+    assert len(w.trajectory) == len(g["traj_t"]) and len(calls) > 0
+    p = np.stack([b.p.detach().numpy() for b in bodies]); v = np.stack([b.v.detach().numpy() for b in bodies])
+    assert np.abs(p - g["traj_p"][-1]).max() < 1e-8 and np.abs(v - g["traj_v"][-1]).max() < 1e-8
+    loss = sum((b.pos ** 2).sum() for b in bodies)
+    grad = torch.autograd.grad(loss, params)[0]
+    assert abs(float(grad) - float(g["grad_0"])) < 1e-5 * abs(float(g["grad_0"])), (float(grad), float(g["grad_0"]))
