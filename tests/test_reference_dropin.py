@@ -1,4 +1,5 @@
-"""CPU, build container only: boundary B1 exercised by the REFERENCE's own code.
+"""CPU, build container only: the drop-in boundaries B1 (LCPFunction) and B2' (contact handler) exercised by the
+REFERENCE's own code.
 
 BASELINE.json configs[0] is the reference's CPU case: lcp_physics' 2-D world (Circle bouncing on a Rect, analytic
 contacts, `lcp_physics/physics/world.py`, `engines.py:31-83`), 50 steps forward + backward.  Here that world runs
@@ -95,3 +96,51 @@ def test_reference_3d_world_on_the_builds_lcp_kernels():
     loss = sum((b.pos ** 2).sum() for b in bodies)
     grad = torch.autograd.grad(loss, params)[0]
     assert abs(float(grad) - float(g["grad_0"])) < 1e-5 * abs(float(g["grad_0"])), (float(grad), float(g["grad_0"]))
+
+
+def test_reference_3d_world_on_the_builds_contact_kernels():
+    """Boundary B2' (contacts.py:21-26, looked up at world.py:52): the reference's World3D with its contact handler
+    replaced by one that runs this build's broad + narrow phase (csrc/narrowphase.hip through the emulator) for the
+    pair it is called with.  The kernel's contacts carry no autograd graph, so the trajectory is compared (a tilted box
+    dropped on the floor: rejected attempts, dt halving, a time-of-contact event, sliding), not the gradient."""
+    from oracle import refshim
+    refshim.install()
+    from oracle.gen import scenes
+    from sdf_physics.physics3d.bodies import SDFBox, SDFCylinder
+    from sdf_physics.physics3d.world import World3D
+    from diffsdfsim_amd.engine import BatchEngine
+
+    class KernelContactHandler:
+        def __call__(self, args, geom1, geom2):
+            if geom1 in geom2.no_contact:
+                return
+            world = args[0]
+            ids = (geom1.body, geom2.body)
+            bs = [world.bodies[i] for i in ids]
+            one = lambda rows: np.stack([np.asarray(r, np.float64) for r in rows])[None]
+            prm = [b.dims.detach().numpy() if isinstance(b, SDFBox) else
+                   np.array([float(b.rad), float(b.height) if isinstance(b, SDFCylinder) else 0.0, 0.0]) for b in bs]
+            spec = dict(pose=one([b.p.detach().numpy() for b in bs]), vel=np.zeros((1, 2, 6)), mass=np.ones((1, 2)),
+                        inertia=np.tile(np.eye(3), (1, 2, 1, 1)), restitution=np.zeros((1, 2)), fric=np.zeros((1, 2)),
+                        fext=np.zeros((1, 2, 6)), shape_prm=one(prm), mesh_id=np.arange(2, dtype=np.int32)[None],
+                        shape_type=np.array([[0 if isinstance(b, SDFBox) else (2 if isinstance(b, SDFCylinder) else 1) for b in bs]], np.int32),
+                        meshes=[(b.verts.detach().numpy(), b.faces.numpy()) for b in bs])
+            E = BatchEngine(spec, backend=emu.EmuBackend(), eps=world.eps, tol=world.tol, fric_dirs=world.fric_dirs,
+                            strict_no_pen=False)      # its constructor runs dss_find_contacts at the given poses
+            t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.double)
+            if int(E.get("invalid")[0]):                # penetration beyond tol: the world only needs to see that
+                world.contacts.append(((t([0.0, 1.0, 0.0]), t(np.zeros(3)), t(np.zeros(3)), t(1.0)), ids[0], ids[1]))
+                return
+            n, body, geom = int(E.get("nc")[0]), E.get("c_body")[0], E.get("c_geom")[0]
+            for c in range(n):
+                world.contacts.append(((t(geom[0:3, c]), t(geom[3:6, c]), t(geom[6:9, c]), t(geom[9, c])),
+                                       ids[body[0, c]], ids[body[1, c]]))
+
+    g = np.load(os.path.join(GOLDEN, "rollout_boxdrop.npz"))
+    bodies, joints, _params = scenes.box_drop(seed=7, requires_grad=False)
+    w = World3D(bodies, joints, contact_callback=KernelContactHandler, time_of_contact_diff=True)
+    for _ in range(12):
+        w.step(fixed_dt=True)
+    assert len(w.trajectory) == len(g["traj_t"])
+    p = np.stack([b.p.detach().numpy() for b in bodies]); v = np.stack([b.v.detach().numpy() for b in bodies])
+    assert np.abs(p - g["traj_p"][-1]).max() < 1e-7 and np.abs(v - g["traj_v"][-1]).max() < 1e-7
