@@ -1,5 +1,5 @@
-"""CPU, build container only: the drop-in boundaries B1 (LCPFunction) and B2' (contact handler) exercised by the
-REFERENCE's own code.
+"""CPU, build container only: the drop-in boundaries B1 (LCPFunction), B2 (engine plug-in) and B2' (contact handler)
+exercised by the REFERENCE's own code.
 
 BASELINE.json configs[0] is the reference's CPU case: lcp_physics' 2-D world (Circle bouncing on a Rect, analytic
 contacts, `lcp_physics/physics/world.py`, `engines.py:31-83`), 50 steps forward + backward.  Here that world runs
@@ -144,3 +144,62 @@ def test_reference_3d_world_on_the_builds_contact_kernels():
     assert len(w.trajectory) == len(g["traj_t"])
     p = np.stack([b.p.detach().numpy() for b in bodies]); v = np.stack([b.v.detach().numpy() for b in bodies])
     assert np.abs(p - g["traj_p"][-1]).max() < 1e-7 and np.abs(v - g["traj_v"][-1]).max() < 1e-7
+
+
+def test_reference_3d_world_on_the_builds_engine_plugin():
+    """Boundary B2 (engines.py:16-19, looked up at world.py:51): the reference's World3D with `engine=` an Engine whose
+    solve_dynamics(world, dt) hands the world's state and contact list to dss_solve_dynamics (assembly + the
+    contact-structured LCP, csrc/step.hip + lcp_contact.hip through the emulator) and returns the new velocities.
+    Values only, so the trajectory is compared: a box on the floor shoved sideways until friction saturates."""
+    import ctypes
+    from oracle import refshim
+    refshim.install()
+    from oracle.gen import scenes
+    from sdf_physics.physics3d.world import World3D
+    from diffsdfsim_amd.engine import BatchEngine
+
+    class KernelEngine:
+        def __init__(self):
+            self.E = None
+
+        def solve_dynamics(self, world, dt):
+            bs = world.bodies
+            nb = len(bs)
+            one = lambda rows: np.stack([np.asarray(r, np.float64) for r in rows])[None]
+            if self.E is None:
+                Je = world.Je().detach().numpy()[None]
+                spec = dict(pose=one([b.p.detach().numpy() for b in bs]), vel=np.zeros((1, nb, 6)), mass=np.ones((1, nb)),
+                            inertia=np.tile(np.eye(3), (1, nb, 1, 1)), restitution=np.zeros((1, nb)), fric=np.zeros((1, nb)),
+                            fext=np.zeros((1, nb, 6)), shape_prm=one([b.dims.detach().numpy() for b in bs]),
+                            shape_type=np.zeros((1, nb), np.int32), mesh_id=np.arange(nb, dtype=np.int32)[None],
+                            meshes=[(b.verts.detach().numpy(), b.faces.numpy()) for b in bs], Je=Je)
+                self.E = BatchEngine(spec, backend=emu.EmuBackend(), eps=world.eps, tol=world.tol, fric_dirs=world.fric_dirs,
+                                     strict_no_pen=False, maxc=64)
+            E = self.E
+            A = E.arr
+            A["pose"][...] = one([b.p.detach().numpy() for b in bs]); A["vel"][...] = one([b.v.detach().numpy() for b in bs])
+            A["mass"][...] = [[float(b.mass) for b in bs]]
+            A["inertia"][...] = one([b.ang_inertia.detach().numpy().reshape(9) for b in bs])
+            A["restitution"][...] = [[float(b.restitution) for b in bs]]; A["fric"][...] = [[float(b.fric_coeff) for b in bs]]
+            A["fext"][...] = world.apply_forces(world.t).detach().numpy().reshape(1, nb, 6)
+            n = len(world.contacts)
+            A["nc"][0] = n
+            for c, ((nr, p1, p2, pen), i1, i2) in enumerate(world.contacts):
+                A["c_body"][0, :, c] = (i1, i2)
+                A["c_geom"][0, 0:3, c] = nr.detach().numpy(); A["c_geom"][0, 3:6, c] = p1.detach().numpy()
+                A["c_geom"][0, 6:9, c] = p2.detach().numpy(); A["c_geom"][0, 9, c] = float(pen)
+            A["dt_try"][0] = float(dt); A["active"][0] = 1
+            rc = E.be.lib.dss_solve_dynamics(ctypes.byref(E.W), ctypes.c_void_p(E.be.ptr(E.lcp_ws)),
+                                             ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream())
+            A["active"][0] = 0
+            assert rc == 0
+            return torch.tensor(-A["x"][0].copy())
+
+    g = np.load(os.path.join(GOLDEN, "rollout_stack1.npz"))
+    bodies, joints, _params = scenes.box_stack(nbox=1, seed=3, vel_scale=1.0, push=2.0, requires_grad=False)
+    w = World3D(bodies, joints, engine=KernelEngine, time_of_contact_diff=True)
+    for _ in range(4):
+        w.step(fixed_dt=True)
+    assert len(w.trajectory) == len(g["traj_t"])
+    p = np.stack([b.p.detach().numpy() for b in bodies]); v = np.stack([b.v.detach().numpy() for b in bodies])
+    assert np.abs(p - g["traj_p"][-1]).max() < 1e-8 and np.abs(v - g["traj_v"][-1]).max() < 1e-8
