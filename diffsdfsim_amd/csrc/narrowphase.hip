@@ -39,7 +39,10 @@ using namespace dss;
 constexpr int NT = 256;
 constexpr int MAX_CPT = 8;       // moving candidates per thread of a group: HCAP <= BT * MAX_CPT
 constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
-constexpr int WAVE_ITEM_MAX_FACES = 32 * 256;   // items that search a bigger mesh take a whole workgroup (WaveGroup::CHCAP runs)
+// Every item starts on a single wavefront, whatever the size of the mesh it searches: the culling boxes of the 176 k-face
+// floor are 688 tests (11 rounds of 64 lanes), after which the item is as small as any other, and a workgroup item keeps
+// four wavefronts busy for what is mostly a serial chain.  Items that outgrow the wavefront's scratch are deferred.
+constexpr int WAVE_ITEM_MAX_FACES = 1 << 30;
 
 __device__ inline int npairs_of(int nb) { return nb * (nb - 1); }
 __device__ inline void pair_of(int dp, int nb, int &a, int &b)
@@ -222,7 +225,7 @@ using WaveGroup = Group<64, 384, 32>;
 
 template <class G> struct ScratchT {
     int wave_tot[G::NW];
-    int woff[G::CHCAP * 4];
+    int woff[G::BT == 64 ? 1 : G::CHCAP * 4];   // (workgroup scan only)
     int vote[2][G::NW];
     int red_i[G::BT];
     double red_d[G::BT];
@@ -643,7 +646,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     auto test_face = [&](int f, double pqr[3][3]) -> int {
         return cull_face(m_fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
     };
-    if (G::BT == 64 && nch <= G::CHCAP) {
+    if (G::BT == 64) {
         // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
         // flight, survivors packed in ascending order into LDS; (b) the full test on dense lanes.
         int npass = 0;
@@ -651,8 +654,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             const int ch = base + tid;
             const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6);
             const int slot = compact_slot(hit, npass, S);
-            if (slot >= 0) S.hidx[slot] = ch;
+            if (slot >= 0 && slot < G::HCAP) S.hidx[slot] = ch;
         }
+        if (npass > G::HCAP) return 1;   // more runs in reach than the wavefront's list holds: a workgroup takes the item
         G::sync();
         int *surv = reinterpret_cast<int *>(S.hp);
         constexpr int SCAP = (int)(sizeof(S.hp) / sizeof(int)) - 4 * 64;
