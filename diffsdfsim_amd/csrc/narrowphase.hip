@@ -429,7 +429,11 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             G::sync();
             return;
         }
-        // supporting-plane test over all triples of distinct points
+        // supporting-plane test over all triples of distinct points.  A point that lies in the triangle of three others
+        // (inside it or on one of its edges) is no hull vertex, whatever planes it helps to support: Qhull reports the
+        // extreme points only, a level-set mesh puts rows of equidistant vertices on every straight edge.
+        for (int q = tid; q < mu; q += G::BT) S.red_d[q] = 0.0;      // 1 = lies in a triangle of other points
+        G::sync();
         const int ntri = mu * mu * mu;
         for (int e = tid; e < ntri; e += G::BT) {
             const int iu = e / (mu * mu), ju = (e / mu) % mu, ku = e % mu;
@@ -459,11 +463,27 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                 const double sd = (n[0] * (P.hp(q, 0) - P.hp(i, 0)) + n[1] * (P.hp(q, 1) - P.hp(i, 1)) + n[2] * (P.hp(q, 2) - P.hp(i, 2))) / ln;
                 pos |= sd > tolf; neg |= sd < -tolf;
             }
+#if DSS_ALL_SHAPES
+            for (int qu = 0; qu < mu; ++qu) {
+                const int q = S.red_i[qu];
+                if (q == i || q == j || q == k) continue;
+                const double w[3] = {P.hp(q, 0) - P.hp(i, 0), P.hp(q, 1) - P.hp(i, 1), P.hp(q, 2) - P.hp(i, 2)};
+                if (fabs(n[0] * w[0] + n[1] * w[1] + n[2] * w[2]) / ln > tolf) continue;      // not in the triangle's plane
+                // barycentric coordinates of q in (i, j, k): areas of the sub-triangles over the area of the triangle
+                double c1[3], c2[3];
+                cross(w, v, c1);
+                cross(u, w, c2);
+                const double bj = (c1[0] * n[0] + c1[1] * n[1] + c1[2] * n[2]) / (ln * ln);
+                const double bk = (c2[0] * n[0] + c2[1] * n[1] + c2[2] * n[2]) / (ln * ln);
+                if (bj >= -1e-9 && bk >= -1e-9 && 1.0 - bj - bk >= -1e-9) S.red_d[qu] = 1.0;
+            }
+#endif
             if (!(pos && neg)) { P.setf(i, 1); P.setf(j, 1); P.setf(k, 1); }
         }
         G::sync();
 #if DSS_ALL_SHAPES
         for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
+        for (int qu = tid; qu < mu; qu += G::BT) if (S.red_d[qu] != 0.0) P.setf(S.red_i[qu], 0);
         G::sync();
 #endif
         return;

@@ -69,7 +69,7 @@ __device__ inline void view_slot(const DssWorld &W, int sc, int k, SlotView &v)
 // (contact_tail: one query, two rotations), so their three passes differentiate that half with the head as constants;
 // x1 appears only in rel = p1 + x1 - x2, hence d/dx1 = -d/dx2 and needs no pass of its own.
 __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
-                            const double *abc, const double *gbar, double *out)
+                            const double *abc, const double *gbar, double *out, double *g_verts)
 {
     constexpr int N = 4;
     typedef Dual<N> D;
@@ -160,6 +160,36 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         else if (grp == 1) { contract(n, nullptr, p2, 11, 3); for (int i = 0; i < 3; ++i) out[4 + i] = -out[11 + i]; }
         else contract(n, nullptr, p2, 17, 3);
     }
+#if DSS_ALL_SHAPES
+    // ---- the triangle's vertices (full variant): one full pass per vertex, seeds = its three coordinates -----------
+    // Level-set meshes have no per-vertex parameter tangent (vgrad = 0); their shape gradient flows through the vertex
+    // positions themselves and is chained to the parameters by the mesher's backward (MeshSDF, bodies.py:680-702).
+    if (g_verts) {
+        for (int vtx = 0; vtx < 3; ++vtx) {
+            BodyG<D> B1, B2;
+            D pr1[3], pr2[3];
+            for (int i = 0; i < 4; ++i) { B1.q[i] = D(P1[i]); B2.q[i] = D(P2[i]); }
+            for (int i = 0; i < 3; ++i) { B1.pos[i] = D(P1[4 + i]); B2.pos[i] = D(P2[4 + i]); pr1[i] = D(prm1[i]); pr2[i] = D(prm2[i]); }
+            make_shape(B1.shape, ty1, pr1, aux1);
+            make_shape(B2.shape, ty2, pr2, aux2);
+            D tri[3][3];
+            for (int v = 0; v < 3; ++v)
+                for (int i = 0; i < 3; ++i) {
+                    D d(tv[v][i]);
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl) if (v == vtx && sl == i) d.d[sl] = 1.0;
+                    tri[v][i] = d;
+                }
+            D n[3], p1[3], p2[3], pen;
+            contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable);
+            for (int s = 0; s < 3; ++s) {
+                double acc = 0.0;
+                for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + gbar[3 + i] * p1[i].d[s] + gbar[6 + i] * p2[i].d[s];
+                atomicAdd(g_verts + (size_t)(voff + fv[vtx]) * 3 + s, acc);
+            }
+        }
+    }
+#endif
 }
 
 // Ordered per-body sums of per-contact pieces:
@@ -312,7 +342,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         double gb[9], out[20];
         for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
         const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
-        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out);
+        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out, A.g_verts);
         for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
     }
     __syncthreads();

@@ -258,7 +258,7 @@ class BatchEngine:
     # -- backward ----------------------------------------------------------------------------------
     def _adjoint(self):
         if getattr(self, "adj", None) is None:
-            shp = abi.adjoint_shapes(self.B, self.nb, self.maxc, self.fd)
+            shp = abi.adjoint_shapes(self.B, self.nb, self.maxc, self.fd, int(self.arr["verts"].shape[0]))
             kinds = dict(abi.ADJ_FIELDS)
             self.adj = {n: self.be.zeros(s, abi.NP_DTYPE[kinds[n]]) for n, s in shp.items()}
             A = abi.DssAdjoint()

@@ -4,8 +4,8 @@ Same constructor arguments and attributes as the reference (``p``, ``pos``, ``ro
 ``faces``, ``dims``/``rad``, ``restitution``, ``fric_coeff``, ``add_force``, ``add_no_contact``, ``query_sdfs``).
 Parameters are torch tensors and may require grad; geometry kernels run on the HIP device.
 ``custom_mesh=True`` gives the reference's analytic meshes; ``custom_mesh=False`` meshes the unit SDF with
-marching cubes on the device like ``SDF3D._create_mesh`` (bodies.py:706-711; the stepper does not yet carry
-shape-parameter gradients through those vertices).  ``custom_inertia=False`` integrates the mesh (dss_mesh_inertia).
+marching cubes on the device like ``SDF3D._create_mesh`` (bodies.py:706-711); the mesh stays differentiable w.r.t. the
+body's parameters (MeshSDF backward) and the stepper returns the adjoint of its vertices.  ``custom_inertia=False`` integrates the mesh (dss_mesh_inertia).
 """
 import math
 
@@ -92,14 +92,20 @@ class Body3D:
 
     def _marching_cubes_mesh(self):
         """`SDF3D._create_mesh` (bodies.py:706-711): unit SDF on 128^3 -> marching cubes -> vertices * scale."""
-        scale = float(self.scale.detach())
-        unit = torch.cat([self.shape_prm().detach().reshape(-1).to(torch.float64), torch.tensor([self.shape_aux()], dtype=torch.float64)]) / scale
+        # kept differentiable: unit parameters and scale are functions of the body's parameters, the mesher's backward is
+        # the MeshSDF rule (bodies.py:680-702); `verts_t` is what a world hands to the stepper as a differentiable input
+        prm = self.shape_prm().reshape(-1).to(torch.float64)
+        unit = torch.cat([prm, torch.tensor([self.shape_aux()], dtype=torch.float64)]) / self.scale
         v, f = meshsdf.primitive_mesh(self.shape_type, unit, res=128)
-        v = (v.detach() * scale).cpu().numpy()
+        self.verts_t = v * self.scale.to(v.device)
+        v = self.verts_t.detach().cpu().numpy()
         return v, f.cpu().numpy().astype(np.int64), np.zeros_like(v)
 
     def _mesh_ang_inertia(self, mass):
         """`SDF3D._get_ang_inertia` (bodies.py:713-714): volume integrals of the body's own mesh (values only)."""
+        vt = getattr(self, "verts_t", None)
+        if vt is not None and vt.requires_grad:       # differentiable like the reference's get_ang_inertia (autograd there)
+            return mass_properties.mesh_inertia_diff(vt, torch.as_tensor(self.faces_np), mass).cpu()
         return mass_properties.mesh_inertia(self.verts_np, self.faces_np, float(torch.as_tensor(mass).detach())).cpu()
 
 

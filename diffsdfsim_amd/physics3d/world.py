@@ -23,8 +23,11 @@ PARAMS = ("mass", "inertia", "restitution", "fric", "fext", "shape_prm")
 
 class _StepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm):
+    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm, verts=None):
+        # verts: the mesh table's vertices [NV,3] as a differentiable input (level-set meshes: their shape gradient flows
+        # through the vertex positions); the engine already holds their values, only the adjoint is produced
         E = world.engine
+        ctx.has_verts = verts is not None
         # upload only what changed since the last step: parameters are usually the same tensors all along, and the
         # state handed in is usually the very tensor the previous step handed out (the engine still holds its values)
         seen = world.__dict__.setdefault("_uploaded", {})
@@ -52,8 +55,9 @@ class _StepFn(torch.autograd.Function):
             adj["a_last_dt"].zero_()
             adj["cur_slot"].copy_(E.arr["nsub"] - 1)
         w._bw_next = ctx.index - 1
-        for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm"):
+        for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm", "g_verts"):
             adj[k].zero_()
+        E.A.g_verts = E.be.ptr(adj["g_verts"]) if ctx.has_verts else None
         adj["a_pose"].copy_(g_pose)
         adj["a_vel"].copy_(g_vel)
         first = ctx.index == 0
@@ -61,15 +65,15 @@ class _StepFn(torch.autograd.Function):
         E.backward_sweep(ctx.att + (1 if first else 0))
         return (None, None, adj["a_pose"].clone(), adj["a_vel"].clone(), adj["g_mass"].clone(),
                 adj["g_inertia"].reshape(E.B, E.nb, 3, 3).clone(), adj["g_rest"].clone(), adj["g_fric"].clone(),
-                adj["g_fext"].clone(), adj["g_prm"].clone())
+                adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None)
 
 
 class BatchWorld3D:
     """B independent scenes stepped in lock step on one HIP device (the capability BASELINE.json adds).
 
     ``spec``: BatchEngine spec (see diffsdfsim_amd.scenes).  ``params``: optional dict of torch tensors
-    (mass [B,nb], inertia [B,nb,3,3], restitution, fric [B,nb], fext [B,nb,6], shape_prm [B,nb,3]) that may
-    require grad; ``pose`` / ``vel`` are the current state tensors (autograd-connected)."""
+    (mass [B,nb], inertia [B,nb,3,3], restitution, fric [B,nb], fext [B,nb,6], shape_prm [B,nb,3]; optionally verts
+    [NV,3], the pooled mesh vertices, for shape gradients through level-set meshes) that may require grad; ``pose`` / ``vel`` are the current state tensors (autograd-connected)."""
 
     def __init__(self, spec, params=None, dt=Defaults3D.DT, eps=Defaults3D.EPSILON, tol=Defaults3D.TOL,
                  fric_dirs=Defaults3D.FRIC_DIRS, strict_no_penetration=True, time_of_contact_diff=True, device=None,
@@ -106,7 +110,8 @@ class BatchWorld3D:
             return hit[2]
         self.pose, self.vel = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
                                             to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
-                                            to("fext", P["fext"]), to("shape_prm", P["shape_prm"]))
+                                            to("fext", P["fext"]), to("shape_prm", P["shape_prm"]),
+                                            to("verts", P["verts"]) if P.get("verts") is not None else None)
         up = self.__dict__.setdefault("_uploaded", {})
         up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
         return self.engine.get("nc") > 0
@@ -146,10 +151,18 @@ class World3D(BatchWorld3D):
             for o in b.no_contact:
                 nocon[i, idx[id(o)]] = 1
         st = lambda f: torch.stack([f(b) for b in bodies])[None]
+
+        def verts_param():       # pooled mesh vertices as a differentiable input, if any body's mesh depends on a parameter
+            vts = [getattr(b, "verts_t", None) for b in bodies]
+            if not any(v is not None and v.requires_grad for v in vts):
+                return {}
+            dev = next(v.device for v in vts if v is not None)
+            return dict(verts=torch.cat([v if v is not None else torch.as_tensor(b.verts_np, device=dev) for v, b in zip(vts, bodies)]))
+        self._verts_param = verts_param
         self._ptensors = lambda t: dict(
             mass=st(lambda b: b.mass.reshape(())), inertia=st(lambda b: b.ang_inertia),
             restitution=st(lambda b: b.restitution.reshape(())), fric=st(lambda b: b.fric_coeff.reshape(())),
-            fext=st(lambda b: b.apply_forces(t)), shape_prm=st(lambda b: b.shape_prm()))
+            fext=st(lambda b: b.apply_forces(t)), shape_prm=st(lambda b: b.shape_prm()), **self._verts_param())
         P = self._ptensors(0.0)
         npd = lambda x: x.detach().cpu().numpy()
         spec = dict(pose=npd(st(lambda b: b.p)), vel=npd(st(lambda b: b.v)), mass=npd(P["mass"]), inertia=npd(P["inertia"]),

@@ -93,7 +93,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
 
 ADJ_FIELDS = [
     ("a_pose", "pd"), ("a_vel", "pd"), ("a_geom", "pd"), ("a_last_dt", "pd"), ("a_dt", "pd"),
-    ("g_mass", "pd"), ("g_inertia", "pd"), ("g_rest", "pd"), ("g_fric", "pd"), ("g_fext", "pd"), ("g_prm", "pd"),
+    ("g_mass", "pd"), ("g_inertia", "pd"), ("g_rest", "pd"), ("g_fric", "pd"), ("g_fext", "pd"), ("g_prm", "pd"), ("g_verts", "pd"),
     ("cur_slot", "pi"), ("lo_slot", "pi"), ("bw_active", "pi"),
     ("a_x", "pd"), ("dMblk", "pd"), ("dpvec", "pd"), ("dcop", "pd"), ("cscr", "pd"), ("bw_nc", "pi"),
 ]
@@ -103,12 +103,12 @@ class DssAdjoint(ctypes.Structure):
     _fields_ = [(n, _P) for n, k in ADJ_FIELDS]
 
 
-def adjoint_shapes(B, nb, maxc, fd):
+def adjoint_shapes(B, nb, maxc, fd, NV=1):
     NFc = 3 * (1 + fd // 2) + 8
     return {
         "a_pose": (B, nb, 7), "a_vel": (B, nb, 6), "a_geom": (B, 10, maxc), "a_last_dt": (B,), "a_dt": (B,),
         "g_mass": (B, nb), "g_inertia": (B, nb, 9), "g_rest": (B, nb), "g_fric": (B, nb), "g_fext": (B, nb, 6),
-        "g_prm": (B, nb, 3), "cur_slot": (B,), "lo_slot": (B,), "bw_active": (B,),
+        "g_prm": (B, nb, 3), "g_verts": (NV, 3), "cur_slot": (B,), "lo_slot": (B,), "bw_active": (B,),
         "a_x": (B, 6 * nb), "dMblk": (B, nb, 36), "dpvec": (B, 6 * nb), "dcop": (B, NFc, maxc),
         "cscr": (B, 56, maxc), "bw_nc": (B,),
     }

@@ -236,6 +236,9 @@ typedef struct DssAdjoint {
     double *a_last_dt;       /* [B] adjoint of World.last_dt carried to the sub-step that produced it */
     double *a_dt;            /* [B] scratch: adjoint of dt_ of the sub-step being processed */
     double *g_mass, *g_inertia, *g_rest, *g_fric, *g_fext, *g_prm;
+    double *g_verts;         /* [NV][3] adjoint of the mesh table's vertices (the contact point is a barycentric combination of
+                                a triangle's vertices, contacts.py:165-171); accumulated with atomics by the full kernel
+                                variant only (DssWorld.shape_rare), so that level-set meshes carry shape gradients; may be NULL */
     int *cur_slot, *lo_slot;
     /* scratch */
     int *bw_active;          /* [B] */

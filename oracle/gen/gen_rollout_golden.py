@@ -136,6 +136,9 @@ CASES = {
     # World3D.step does not get past the first sphere-in-bowl contact (dt halving without end); the bowl is pinned at the
     # query level (sdf_query.npz).
     "rollout_rounded": (lambda: scenes.rounded_drop("rounded"), dict(nsteps=10, store_mesh=False)),
+    # the same scene with d sum|pos_T|^2 / d dims: through the SDF, through the level-set mesh (MeshSDF backward) and
+    # through the inertia integrated over that mesh
+    "rollout_rounded_grad": (lambda: scenes.rounded_drop("rounded", requires_grad=True), dict(nsteps=10, store_mesh=False)),
     "rollout_brick": (lambda: scenes.rounded_drop("brick"), dict(nsteps=10, store_mesh=False)),
 }
 

@@ -112,7 +112,7 @@ def big_box(requires_grad=True, gap=5e-4, mu=0.5, rest=0.0):
     return [floor, b], [TotalConstraint3D(floor)], [dims]
 
 
-def rounded_drop(kind="rounded", mu=0.4, rest=0.3):
+def rounded_drop(kind="rounded", mu=0.4, rest=0.3, requires_grad=False):
     """A tilted SDFBoxRounded / SDFBrick (level-set mesh from the marching-cubes stand-in, inertia from that mesh)
     dropped onto the floor."""
     from sdf_physics.physics3d.bodies import SDFBox, SDFBoxRounded, SDFBrick
@@ -122,9 +122,10 @@ def rounded_drop(kind="rounded", mu=0.4, rest=0.3):
     floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
     pos = torch.tensor([0.25, 0.1, -0.2, 0.0, 0.5, 0.0], dtype=torch.double)
     vel = torch.tensor([0.3, -0.1, 0.2, 0.6, -0.4, 0.1], dtype=torch.double)
+    dims = torch.tensor([0.6, 0.5, 0.7] if kind == "rounded" else [0.7, 0.6, 0.4], dtype=torch.double, requires_grad=requires_grad)
     if kind == "rounded":
-        b = SDFBoxRounded(pos, torch.tensor([0.6, 0.5, 0.7], dtype=torch.double), 0.15, vel=vel, restitution=rest, fric_coeff=mu)
+        b = SDFBoxRounded(pos, dims, 0.15, vel=vel, restitution=rest, fric_coeff=mu)
     else:
-        b = SDFBrick(pos, torch.tensor([0.7, 0.6, 0.4], dtype=torch.double), 0.12, vel=vel, restitution=rest, fric_coeff=mu)
+        b = SDFBrick(pos, dims, 0.12, vel=vel, restitution=rest, fric_coeff=mu)
     b.add_force(Gravity3D())
-    return [floor, b], [TotalConstraint3D(floor)], []
+    return [floor, b], [TotalConstraint3D(floor)], ([dims] if requires_grad else [])
