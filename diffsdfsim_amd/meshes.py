@@ -1,10 +1,10 @@
 """Analytic surface meshes for the primitive SDF bodies (host side, built once per body).
 
 These are the ``custom_mesh=True`` meshes of the reference
-(`sdf_physics/physics3d/bodies.py:799-854` box, `:996-1009` sphere, `:939-976` cylinder):
+(`sdf_physics/physics3d/bodies.py:799-854` box, `:996-1009` sphere, `:939-976` cylinder, `:1029-1065` bowl):
 the contact search walks the triangles of body 1's mesh against body 2's SDF, so the
-mesh defines the candidate set.  Mesh extraction by marching cubes (the reference's
-default, via the un-vendored ``ev_sdf_utils``) is a "next" row of SURVEY.md §8f.
+mesh defines the candidate set.  The reference's default, level-set meshes by marching
+cubes, is in ``meshsdf.py`` (device kernels).
 
 All functions return ``(verts [V,3] float64, faces [F,3] int64)`` as numpy arrays in the
 body frame; ``box_mesh`` additionally returns, per vertex and axis, the sign (+1/-1/0) of
