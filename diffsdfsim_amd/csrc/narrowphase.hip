@@ -534,9 +534,11 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                 if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
                 if (best < 0) { best = k; bx = qx; by = qy; continue; }
                 const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
-                // clockwise of the best so far by more than the angular tolerance (|sin| > 1e-9, compared squared), or
+                // clockwise of the best so far by more than the angular tolerance (|sin| > 1e-12, compared squared: Qhull
+                // keeps a vertex that clears its neighbours' edge by 1e-14 of the extent, the rounding noise of exactly
+                // collinear mesh points is 1e-16), or
                 // collinear with it and farther
-                const double c2 = cr * cr, t2 = 1e-18 * (lb * lq);
+                const double c2 = cr * cr, t2 = 1e-24 * (lb * lq);
                 if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && lq > lb)) { best = k; bx = qx; by = qy; }
             }
             S.red_i[tid] = best;
@@ -550,7 +552,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                             const double ax = P.hp(a, c0) - cx, ay = P.hp(a, c1) - cy;
                             const double qx = P.hp(b, c0) - cx, qy = P.hp(b, c1) - cy;
                             const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
-                            const double c2 = cr * cr, t2 = 1e-18 * (la * lq);
+                            const double c2 = cr * cr, t2 = 1e-24 * (la * lq);
                             if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
                         }
                     }

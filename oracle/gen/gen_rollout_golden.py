@@ -126,6 +126,9 @@ CASES = {
     "rollout_sphere_notoc": (lambda: scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0)), dict(nsteps=24, toc=False)),
     "rollout_stack1": (lambda: scenes.box_stack(nbox=1, seed=3, vel_scale=1.0, push=2.0), dict(nsteps=4)),
     "rollout_stack2": (lambda: scenes.box_stack(nbox=2, seed=4, vel_scale=0.5, push=1.5), dict(nsteps=3)),
+    # BASELINE configs[2] itself at batch 1: floor + 7 stacked boxes (48 velocities, ~560 inequality rows), shoved so that
+    # friction saturates and the gradients are non-zero
+    "rollout_stack7": (lambda: scenes.box_stack(nbox=7, seed=11, vel_scale=0.3, push=1.0), dict(nsteps=3)),
     "rollout_boxdrop": (lambda: scenes.box_drop(seed=7), dict(nsteps=12)),
     "rollout_cylinder": (lambda: scenes.cylinder_drop(seed=9), dict(nsteps=10)),
     # long horizon: 100 outer steps, 245 sub-steps, several bounces with time-of-contact events, coming to rest

@@ -37,3 +37,15 @@ if len(sys.argv) > 3:
     print("ref"); print(ref[np.argsort(ref[:, 3])][:, [0, 1, 2, 3, 4, 5, 9]])
     print("ref bodies", g["traj_body"][j - 1][:g["traj_nc"][j - 1]].tolist())
     print("pc_stats", E.get("pc_stats")[0].tolist())
+if len(sys.argv) > 4:      # per-pair contact counts at sub-step j: ours vs reference
+    j = int(sys.argv[3])
+    tb = E.get("tp_body")
+    from collections import Counter
+    ours = Counter(map(tuple, tb[j, 0][:, :tnc[j, 0]].T.tolist()))
+    ref = Counter(map(tuple, g["traj_body"][j - 1][:g["traj_nc"][j - 1]].tolist()))
+    for k in sorted(set(ours) | set(ref)):
+        if ours[k] != ref[k]:
+            print("pair", k, "ours", ours[k], "ref", ref[k])
+            a = tg[j, 0][:, :tnc[j, 0]].T[[i for i, p in enumerate(tb[j, 0][:, :tnc[j, 0]].T.tolist()) if tuple(p) == k]]
+            b = g["traj_geom"][j - 1][:g["traj_nc"][j - 1]][[i for i, p in enumerate(g["traj_body"][j - 1][:g["traj_nc"][j - 1]].tolist()) if tuple(p) == k]]
+            print("ours p1,pen\n", a[np.lexsort(a[:, 3:6].T[::-1])][:, [0, 1, 2, 3, 4, 5, 9]]); print("ref p1,pen\n", b[np.lexsort(b[:, 3:6].T[::-1])][:, [0, 1, 2, 3, 4, 5, 9]])
