@@ -348,6 +348,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         var[d] = block_sum(acc, S) / (m - 1);
     }
     const double tolf = 1e-12 * (1.0 + amax);
+    const double dtol2 = (1.6e-15 * (1.0 + amax)) * (1.6e-15 * (1.0 + amax));   // (distance tolerance of the 2-D hull)^2
     // farthest point B from A = point 0, then C farthest from line AB
     const double A[3] = {P.hp(0, 0), P.hp(0, 1), P.hp(0, 2)};
     double key = -1.0; int ki = -1;
@@ -534,11 +535,12 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                 if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
                 if (best < 0) { best = k; bx = qx; by = qy; continue; }
                 const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
-                // clockwise of the best so far by more than the angular tolerance (|sin| > 1e-12, compared squared: Qhull
-                // keeps a vertex that clears its neighbours' edge by 1e-14 of the extent, the rounding noise of exactly
-                // collinear mesh points is 1e-16), or
-                // collinear with it and farther
-                const double c2 = cr * cr, t2 = 1e-24 * (lb * lq);
+                // clockwise of the best so far by more than round-off, or collinear with it and farther.  Measured like
+                // Qhull measures it: the nearer of the two points clears the line through the farther one by more than
+                // a few ulps of the cluster's extent (Qhull merges facets flatter than that and keeps every vertex that
+                // sticks out more: contact points along an edge are collinear to 1e-9 .. 1e-12 only, and whether such a
+                // point survives changes the contact set)
+                const double c2 = cr * cr, t2 = dtol2 * fmax(lb, lq);
                 if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && lq > lb)) { best = k; bx = qx; by = qy; }
             }
             S.red_i[tid] = best;
@@ -552,7 +554,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                             const double ax = P.hp(a, c0) - cx, ay = P.hp(a, c1) - cy;
                             const double qx = P.hp(b, c0) - cx, qy = P.hp(b, c1) - cy;
                             const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
-                            const double c2 = cr * cr, t2 = 1e-24 * (la * lq);
+                            const double c2 = cr * cr, t2 = dtol2 * fmax(la, lq);
                             if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
                         }
                     }
