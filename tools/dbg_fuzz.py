@@ -1,0 +1,23 @@
+"""Dev aid (GPU box): run every tests/golden/tmp_*.npz rollout and report where it leaves the reference."""
+import glob, os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, rollout_helpers as R
+from diffsdfsim_amd.engine import BatchEngine
+for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "tmp_*.npz"))):
+    name = os.path.basename(f)[:-4]
+    g = R.load_rollout(name)
+    nsteps = int(round(float(g["t_final"]) / float(g["dt"])))
+    E = BatchEngine(R.spec_from_golden(g, 1), **R.engine_kwargs(g, max_sub=256, maxc=160, max_pc=32))
+    for _ in range(nsteps):
+        E.step()
+    n = int(E.get("nsub")[0]); T = len(g["traj_t"])
+    tp, tnc = E.get("tp_pose"), E.get("tp_nc")
+    first = None
+    for j in range(1, min(n, T)):
+        dev = np.abs(tp[j, 0] - g["traj_p"][j - 1]).max()
+        if dev > 1e-9 or int(tnc[j, 0]) != int(g["traj_nc"][j - 1]):
+            first = (j, dev, int(tnc[j, 0]), int(g["traj_nc"][j - 1])); break
+    fin = np.abs(E.get("pose")[0] - g["traj_p"][-1]).max() if n == T else float("nan")
+    got = R.param_grads(E, g, 0) if False else None
+    print("%-18s nsub %3d ref %3d  final pose dev %.1e  first deviation %s" % (name, n, T, fin, first))
