@@ -26,6 +26,9 @@
 #ifndef DSS_ALL_SHAPES
 #define DSS_ALL_SHAPES 0
 #endif
+// 3-D hull of a contact cluster with Qhull's vertex semantics (coincident points are one vertex, points in a triangle of
+// others are none).  Needed by every variant: neighbouring faces of an icosphere converge to shared vertices too.
+#define DSS_HULL_EXACT 1
 #include <math.h>
 #include <stdlib.h>
 
@@ -398,7 +401,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             }
         }
     }
-#if DSS_ALL_SHAPES
+#if DSS_HULL_EXACT
     if (!flat3 && m > 2048) {   // beyond what the pairwise duplicate search below is meant for: keep every point
         for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
         G::sync();
@@ -464,7 +467,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                 const double sd = (n[0] * (P.hp(q, 0) - P.hp(i, 0)) + n[1] * (P.hp(q, 1) - P.hp(i, 1)) + n[2] * (P.hp(q, 2) - P.hp(i, 2))) / ln;
                 pos |= sd > tolf; neg |= sd < -tolf;
             }
-#if DSS_ALL_SHAPES
+#if DSS_HULL_EXACT
             for (int qu = 0; qu < mu; ++qu) {
                 const int q = S.red_i[qu];
                 if (q == i || q == j || q == k) continue;
@@ -482,7 +485,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             if (!(pos && neg)) { P.setf(i, 1); P.setf(j, 1); P.setf(k, 1); }
         }
         G::sync();
-#if DSS_ALL_SHAPES
+#if DSS_HULL_EXACT
         for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
         for (int qu = tid; qu < mu; qu += G::BT) if (S.red_d[qu] != 0.0) P.setf(S.red_i[qu], 0);
         G::sync();

@@ -19,5 +19,13 @@ for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "tmp_*.npz"))):
         if dev > 1e-9 or int(tnc[j, 0]) != int(g["traj_nc"][j - 1]):
             first = (j, dev, int(tnc[j, 0]), int(g["traj_nc"][j - 1])); break
     fin = np.abs(E.get("pose")[0] - g["traj_p"][-1]).max() if n == T else float("nan")
-    got = R.param_grads(E, g, 0) if False else None
-    print("%-18s nsub %3d ref %3d  final pose dev %.1e  first deviation %s" % (name, n, T, fin, first))
+    gerr = float("nan")
+    if "grad_0" in g and n == T:
+        E2 = BatchEngine(R.spec_from_golden(g, 1), **R.engine_kwargs(g, max_sub=256, maxc=160, max_pc=32))
+        R.rollout_and_sweep(E2, nsteps)
+        got = R.param_grads(E2, g, 0)
+        errs = []
+        for key in ("grad_%d", "gradB_%d"):
+            errs.append(max(np.abs(gi - g[key % i]).max() / max(np.abs(g[key % i]).max(), 1e-300) for i, gi in enumerate(got)))
+        gerr = min(errs)
+    print("%-18s nsub %3d ref %3d  final pose dev %.1e  grad rel err %.1e  first deviation %s" % (name, n, T, fin, gerr, first))
