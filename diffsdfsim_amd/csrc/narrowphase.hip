@@ -500,13 +500,16 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
     bool collinear = (m < 3);
     int iS = -1;
     if (!collinear) {
-        // start: lexicographic minimum
+        // start: lexicographic minimum.  "Equal" first coordinates are equal to round-off: contact points along a box edge
+        // are collinear in the body frame and pick up 1e-17 of noise in the rotation to the world frame; taking the
+        // bare minimum would start (and keep) a point from the middle of that edge
         double k0 = INFINITY; int k0i = -1;
         for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) < k0) { k0 = P.hp(k, c0); k0i = k; }
         const int i0 = block_argmin(k0, k0i, S);
         const double x0 = P.hp(i0, c0);
         k0 = INFINITY; k0i = -1;
-        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) == x0 && P.hp(k, c1) < k0) { k0 = P.hp(k, c1); k0i = k; }
+        const double xtol = 1.6e-15 * (1.0 + amax);
+        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) <= x0 + xtol && P.hp(k, c1) < k0) { k0 = P.hp(k, c1); k0i = k; }
         iS = block_argmin(k0, k0i, S);
         // collinearity: farthest point from the start, then max distance to that line
         key = -1.0; ki = -1;
