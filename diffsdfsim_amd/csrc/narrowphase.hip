@@ -351,7 +351,10 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         var[d] = block_sum(acc, S) / (m - 1);
     }
     const double tolf = 1e-12 * (1.0 + amax);
-    const double dtol2 = (1.6e-15 * (1.0 + amax)) * (1.6e-15 * (1.0 + amax));   // (distance tolerance of the 2-D hull)^2
+    // distance tolerance of the 2-D hull: Qhull merges a vertex that clears its neighbours' edge by less than ~6e-15 of the
+    // extent (its `_one-merge`); a box that has turned by 4e-15 rad puts its mid-edge contact points 2e-15 off the edge
+    // (dropped there), the smallest excursion seen kept is 4e-11
+    const double dtol = 2e-14 * (1.0 + amax), dtol2 = dtol * dtol;
     // farthest point B from A = point 0, then C farthest from line AB
     const double A[3] = {P.hp(0, 0), P.hp(0, 1), P.hp(0, 2)};
     double key = -1.0; int ki = -1;
@@ -508,7 +511,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         const int i0 = block_argmin(k0, k0i, S);
         const double x0 = P.hp(i0, c0);
         k0 = INFINITY; k0i = -1;
-        const double xtol = 1.6e-15 * (1.0 + amax);
+        const double xtol = dtol;
         for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) <= x0 + xtol && P.hp(k, c1) < k0) { k0 = P.hp(k, c1); k0i = k; }
         iS = block_argmin(k0, k0i, S);
         // collinearity: farthest point from the start, then max distance to that line

@@ -52,6 +52,7 @@ def describe(bodies, g=10.0, store_mesh=True):
         else:
             prm[i, 0] = float(b.rad)
     d["shape_prm"], d["shape_aux"] = prm, aux
+    d["no_contact"] = np.array([[int(o.geom in b.geom.no_contact) for o in bodies] for b in bodies], np.uint8)   # add_no_contact (bodies.py:441-445)
     d["pose0"] = np.stack([b.p.detach().numpy() for b in bodies])
     d["vel0"] = np.stack([b.v.detach().numpy() for b in bodies])
     d["mass"] = np.array([float(b.mass) for b in bodies])

@@ -20,6 +20,8 @@ def spec_from_golden(g, copies=1, level_set_mesh=None):
     for k, b in enumerate(g["fixed"]):
         Je[6 * k:6 * k + 6, 6 * b:6 * b + 6] = np.eye(6)   # TotalConstraint3D.J() = I_6 (constraints.py:131-137)
     extra = dict(shape_aux=rep(g["shape_aux"])) if "shape_aux" in g else {}
+    if "no_contact" in g:
+        extra["no_contact"] = np.asarray(g["no_contact"], np.uint8)
     return dict(extra, pose=rep(g["pose0"]), vel=rep(g["vel0"]), mass=rep(g["mass"]), inertia=rep(g["inertia"]),
                 restitution=rep(g["restitution"]), fric=rep(g["fric"]), fext=rep(g["fext"]),
                 shape_type=rep(g["shape_type"]), shape_prm=rep(g["shape_prm"]), mesh_id=rep(np.arange(nb)),
