@@ -135,6 +135,14 @@ CASES = {
     # long horizon: 100 outer steps, 245 sub-steps, several bounces with time-of-contact events, coming to rest
     "rollout_sphere_long": (lambda: scenes.sphere_drop(seed=1, floor_dims=(4.0, 1.0, 4.0)), dict(nsteps=100)),
     "rollout_bigbox": (lambda: scenes.big_box(), dict(nsteps=3)),
+    # cases that came out of random comparisons against the reference (tools/dbg_fuzz.py): each one exposed a difference
+    # in the thinning stage's hull (coincident points, a mid-edge start vertex, Qhull's merge tolerance) or exercises
+    # bookkeeping no other golden has (pinned body not first, no_contact pairs, sphere against sphere)
+    "rollout_two_spheres": (lambda: scenes.two_spheres(), dict(nsteps=12)),
+    "rollout_sphere_on_box": (lambda: scenes.sphere_on_box(), dict(nsteps=12)),
+    "rollout_floor_last": (lambda: scenes.floor_last(), dict(nsteps=20, fixed=(1,))),
+    "rollout_no_contact": (lambda: scenes.no_contact_pair(), dict(nsteps=6)),
+    "rollout_sphere_roll": (lambda: scenes.sphere_drop(seed=60), dict(nsteps=40)),
     # the remaining primitives (bodies.py:857-885).  SDFBowl has no rollout golden: the reference's bowl evaluates its
     # normal at a point shifted twice (in-place shift in both bowl_sdf and bowl_sdf_grad, bodies.py:99,119), and its own
     # World3D.step does not get past the first sphere-in-bowl contact (dt halving without end); the bowl is pinned at the

@@ -129,3 +129,64 @@ def rounded_drop(kind="rounded", mu=0.4, rest=0.3, requires_grad=False):
         b = SDFBrick(pos, dims, 0.12, vel=vel, restitution=rest, fric_coeff=mu)
     b.add_force(Gravity3D())
     return [floor, b], [TotalConstraint3D(floor)], ([dims] if requires_grad else [])
+
+
+# ---- shape-pair and bookkeeping cases that came out of random comparisons against the reference (tools/dbg_fuzz.py) -------
+def _T(x, g=False):
+    return torch.tensor(x, dtype=torch.double, requires_grad=g)
+
+
+def _imports():
+    from sdf_physics.physics3d.bodies import SDFBox, SDFCylinder, SDFSphere
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+    return SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D
+
+
+def _floor(mu=0.4, rest=0.3):
+    SDFBox = _imports()[0]
+    return SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+
+
+def two_spheres():
+    """Two spheres rolling into each other on the floor: sphere mesh against sphere SDF."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(); r1, r2 = _T(0.3, True), _T(0.25, True)
+    a = SDFSphere([0.0, 0.3005, 0.0], r1, vel=[0, 0, 0, 0.5, 0, 0], custom_mesh=True, custom_inertia=True, restitution=0.3, fric_coeff=0.4)
+    b = SDFSphere([0.62, 0.2505, 0.05], r2, vel=[0, 0, 0, -0.8, 0, 0], custom_mesh=True, custom_inertia=True, restitution=0.3, fric_coeff=0.4)
+    for x in (a, b):
+        x.add_force(Gravity3D())
+    return [f, a, b], [TotalConstraint3D(f)], [r1, r2]
+
+
+def sphere_on_box():
+    """A sphere dropped on a box that rests on the floor (three bodies, box-floor face contact with mid-edge candidates)."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(); d = _T([0.8, 0.4, 0.7], True); r = _T(0.2, True)
+    b = SDFBox([0.0, 0.2005, 0.0], d, custom_mesh=True, custom_inertia=True, restitution=0.2, fric_coeff=0.4)
+    s = SDFSphere([0.1, 0.4 + 0.2 + 0.15, 0.05], r, vel=[0, 0, 0, 0.3, -0.5, 0.1], custom_mesh=True, custom_inertia=True, restitution=0.2, fric_coeff=0.4)
+    for x in (b, s):
+        x.add_force(Gravity3D())
+    return [f, b, s], [TotalConstraint3D(f)], [d, r]
+
+
+def floor_last():
+    """The pinned body is not body 0 (the LCP's closed-form elimination of a pinned leading body does not apply)."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    r = _T(0.3, True)
+    s = SDFSphere([0.0, 0.5, 0.0], r, vel=[0, 0, 2.0, 0.6, 0, 0], custom_mesh=True, custom_inertia=True, restitution=0.4, fric_coeff=0.5)
+    s.add_force(Gravity3D())
+    f = _floor(0.5, 0.4)
+    return [s, f], [TotalConstraint3D(f)], [r]
+
+
+def no_contact_pair():
+    """Two interpenetrating boxes that ignore each other (Body.add_no_contact), both resting on the floor."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(); d1, d2 = _T([0.5, 0.4, 0.5], True), _T([0.4, 0.6, 0.4], True)
+    a = SDFBox([0.0, 0.2005, 0.0], d1, vel=[0, 0, 0, 0.3, 0, 0], custom_mesh=True, custom_inertia=True, restitution=0.1, fric_coeff=0.4)
+    b = SDFBox([0.1, 0.3005, 0.05], d2, vel=[0, 0, 0, -0.2, 0, 0.1], custom_mesh=True, custom_inertia=True, restitution=0.1, fric_coeff=0.4)
+    a.add_no_contact(b)
+    for x in (a, b):
+        x.add_force(Gravity3D())
+    return [f, a, b], [TotalConstraint3D(f)], [d1, d2]

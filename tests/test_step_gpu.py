@@ -110,3 +110,27 @@ def test_config3_scene_gradients_against_reference_autograd():
     assert np.isfinite(mine).all() and err < max(3.0 * spread, 1e-4 * np.abs(a).max()), (err, spread)
     gp = E.be.to_numpy(E.adj["g_prm"])
     assert (gp == gp[:1]).all()
+
+
+@pytest.mark.parametrize("name,nsteps", [("rollout_two_spheres", 12), ("rollout_sphere_on_box", 12), ("rollout_floor_last", 20),
+                                         ("rollout_no_contact", 6), ("rollout_sphere_roll", 40)])
+def test_cases_found_by_random_comparison(name, nsteps):
+    """Scenes kept from random comparisons against the reference (tools/dbg_fuzz.py): sphere against sphere, three
+    bodies, a pinned body that is not body 0, a no_contact pair, a rolling sphere with coincident contact points.  Held:
+    the number of sub-steps, the contact COUNT of every sub-step (the thinning stage must pick Qhull's vertices), poses
+    to 1e-9 and d sum|pos_T|^2 / d parameters to 1e-5 (gradients below 1e-9 in magnitude are not compared)."""
+    g, E = make(name, 2, max_sub=96)
+    R.rollout_and_sweep(E, nsteps)
+    assert int(E.get("overflow").max()) == 0 and (E.get("nsub") == len(g["traj_t"])).all()
+    k = len(g["traj_t"]) - 1
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-9 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
+    tp, tnc = E.get("tp_pose"), E.get("tp_nc")
+    for j in range(1, k + 1):
+        assert np.abs(tp[j, 0] - g["traj_p"][j - 1]).max() < 1e-9
+        assert int(tnc[j, 0]) == int(g["traj_nc"][j - 1]), (j, int(tnc[j, 0]), int(g["traj_nc"][j - 1]))
+    R.check_contacts(E, 1, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
+    got = R.param_grads(E, g, 0)
+    for i, gi in enumerate(got):
+        want = g["grad_%d" % i]
+        if np.abs(want).max() > 1e-9:
+            assert np.abs(gi - want).max() < 1e-5 * np.abs(want).max(), (i, gi, want)
