@@ -1087,6 +1087,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 #endif
         for (int k = tid, r = 0; k < ncon; k += G::BT, ++r) {
             const int kept = get_state(k) == 2;
+#if DSS_ALL_SHAPES
+            if (r < 32)
+#endif
             keptbits |= (unsigned)kept << r;     // round r of this thread: the final stage walks the same (round, thread) grid
             nkeep += kept;
         }
@@ -1111,7 +1114,13 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     } else {
         for (int base = 0, r = 0; base < ncon; base += G::BT, ++r) {
             const int k = base + tid;
-            const int flag = (k < ncon) && ((keptbits >> r) & 1u);
+            // beyond 32 rounds (more than 32 x group size contacts: a level-set face lying flat) the bit mask is full and the
+            // state array, which such a count keeps in global memory, is read instead
+#if DSS_ALL_SHAPES
+            const int flag = (k < ncon) && (r < 32 ? (int)((keptbits >> r) & 1u) : (cstate[k] == 2));
+#else
+            const int flag = (k < ncon) && ((keptbits >> r) & 1u);     // (the lean variant stops at HCAP contacts per cluster)
+#endif
             if (!G::any(flag)) continue;
             const int slot = compact_slot(flag, nout, S);
             if (slot >= 0 && slot < MP) {

@@ -61,7 +61,7 @@ def describe(bodies, g=10.0, store_mesh=True):
     d["fric"] = np.array([float(b.fric_coeff) for b in bodies])
     d["fext"] = np.stack([b.apply_forces(0.0).detach().numpy() for b in bodies])
     for i, b in enumerate(bodies):
-        if not store_mesh and isinstance(b, (SDFBoxRounded, SDFBrick)):
+        if not store_mesh and len(b.faces) > 20000:
             # level-set mesh (128^3 marching cubes, ~10^5 faces): the tests rebuild it with the build's own marching cubes
             # -- the stand-in the reference ran with uses the same case tables -- and check these sizes
             d["meshsize_%d" % i] = np.array([len(b.verts), len(b.faces)])
@@ -151,6 +151,7 @@ CASES = {
     # the same scene with d sum|pos_T|^2 / d dims: through the SDF, through the level-set mesh (MeshSDF backward) and
     # through the inertia integrated over that mesh
     "rollout_rounded_grad": (lambda: scenes.rounded_drop("rounded", requires_grad=True), dict(nsteps=10, store_mesh=False)),
+    "rollout_levelset_box": (lambda: scenes.levelset_box(), dict(nsteps=3, store_mesh=False)),
     "rollout_brick": (lambda: scenes.rounded_drop("brick"), dict(nsteps=10, store_mesh=False)),
 }
 

@@ -190,3 +190,15 @@ def no_contact_pair():
     for x in (a, b):
         x.add_force(Gravity3D())
     return [f, a, b], [TotalConstraint3D(f)], [d1, d2]
+
+
+def levelset_box(mu=0.4, rest=0.1, requires_grad=False):
+    """A box with the reference's DEFAULT mesh and inertia (custom_mesh = custom_inertia = False: 128^3 marching cubes,
+    volume integrals) set down flat on the floor with a small sideways velocity: every face of its bottom side is a
+    contact candidate with the same normal (one cluster of thousands of points for the thinning stage)."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(mu, rest)
+    d = _T([0.6, 0.4, 0.5], requires_grad)
+    b = SDFBox([0.0, 0.2 + 5e-4, 0.0], d, vel=[0, 0, 0, 0.4, 0, 0.1], restitution=rest, fric_coeff=mu)
+    b.add_force(Gravity3D())
+    return [f, b], [TotalConstraint3D(f)], ([d] if requires_grad else [])

@@ -157,3 +157,24 @@ def test_rounded_box_gradient_through_sdf_mesh_and_inertia_matches_reference():
     got = dims.grad.numpy()
     errs = [np.abs(got - g[k]).max() / np.abs(g[k]).max() for k in ("grad_0", "gradB_0")]
     assert min(errs) < 1e-4, (got, g["grad_0"], g["gradB_0"])
+
+
+def test_box_with_the_reference_default_mesh_resting_flat_matches_reference():
+    """SDFBox with custom_mesh = custom_inertia = False (the reference's defaults: level-set mesh, integrated inertia)
+    set down flat on the floor and sliding: every face of its bottom side (~14 000) is a contact with the same normal.
+    The thinning stage works that cluster off in the global scratch and must end with the reference's eight contacts."""
+    from diffsdfsim_amd.engine import BatchEngine
+    g = R.load_rollout("rollout_levelset_box")
+    E = BatchEngine(R.spec_from_golden(g, 2, level_set_mesh(g)), **R.engine_kwargs(g, max_sub=16, maxc=64, max_cand=32768, max_pc=32))
+    assert int(E.W.shape_rare) == 1      # dense mesh on a free body: the full kernel variants
+    for _ in range(3):
+        E.step()
+    assert int(E.get("overflow").max()) == 0 and (E.get("nsub") == len(g["traj_t"])).all()
+    k = len(g["traj_t"]) - 1
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
+    assert int(E.get("pc_stats")[0].reshape(-1, 2)[:, 1].max()) > 5000      # thousands of candidates in one pair
+    tnc = E.get("tp_nc")
+    for j in range(1, k + 1):
+        assert int(tnc[j, 0]) == int(g["traj_nc"][j - 1])
+    for s in (0, 1):
+        R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
