@@ -21,8 +21,9 @@ def level_set_mesh(g):
     from diffsdfsim_amd import meshsdf
 
     def build(i):
-        dims, r = g["shape_prm"][i], float(g["shape_aux"][i])
-        scale = dims.max() * 1.5 / 2
+        dims, r, ty = g["shape_prm"][i], float(g["shape_aux"][i]), int(g["shape_type"][i])
+        # the bodies' scale rules (bodies.py:782, 913, 987, 1019)
+        scale = {1: dims[0] * 1.5, 2: max(dims[0], dims[1] / 2) * 1.5, 5: (dims[0] + dims[1]) * 1.3333}.get(ty, dims.max() * 1.5 / 2)
         v, f = meshsdf.primitive_mesh(int(g["shape_type"][i]), np.concatenate([dims, [r]]) / scale, res=128)
         assert (len(v), len(f)) == tuple(g["meshsize_%d" % i]), "device marching cubes and the golden's mesh differ in size"
         return (v * scale).cpu().numpy(), f.cpu().numpy()

@@ -8,7 +8,12 @@ for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "tmp_*.npz"))):
     name = os.path.basename(f)[:-4]
     g = R.load_rollout(name)
     nsteps = int(round(float(g["t_final"]) / float(g["dt"])))
-    E = BatchEngine(R.spec_from_golden(g, 1), **R.engine_kwargs(g, max_sub=256, maxc=160, max_pc=32))
+    lsm = None
+    if any(k.startswith("meshsize_") for k in g):
+        import test_primitives_gpu as T
+        lsm = T.level_set_mesh(g)
+    kw = dict(max_sub=256, maxc=160, max_pc=128, max_cand=32768) if lsm else dict(max_sub=256, maxc=160, max_pc=32)
+    E = BatchEngine(R.spec_from_golden(g, 1, lsm), **R.engine_kwargs(g, **kw))
     for _ in range(nsteps):
         E.step()
     n = int(E.get("nsub")[0]); T = len(g["traj_t"])
