@@ -139,3 +139,28 @@ def test_body_set_p_and_mass_matrix():
     y0 = float(ball.pos[1])
     w.step(fixed_dt=True)
     assert abs(float(w.pose[0, 1, 5]) - y0) < 0.05 and float(w.pose[0, 1, 5]) > float(g["traj_p"][1][1][5]) + 0.2
+
+
+def test_world3d_three_bodies_gradients_wrt_box_dims_and_sphere_radius():
+    """`rollout_sphere_on_box` (floor, a box on it, a sphere dropped on the box) through the class API: the gradient of
+    sum|pos_T|^2 w.r.t. the box's dims and the sphere's radius flows through shape parameters AND the analytic inertias
+    (torch), against the reference's autograd."""
+    from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, SDFSphere, TotalConstraint3D, World3D
+    g = R.load_rollout("rollout_sphere_on_box")
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=0.3, fric_coeff=0.4)
+    d = torch.tensor(g["param_0"], dtype=torch.float64, requires_grad=True)
+    r = torch.tensor(float(g["param_1"]), dtype=torch.float64, requires_grad=True)
+    box = SDFBox(g["pose0"][1, 4:].tolist(), d, vel=g["vel0"][1].tolist(), restitution=0.2, fric_coeff=0.4)
+    ball = SDFSphere(g["pose0"][2, 4:].tolist(), r, vel=g["vel0"][2].tolist(), restitution=0.2, fric_coeff=0.4)
+    for b in (box, ball):
+        b.add_force(Gravity3D())
+    w = World3D([floor, box, ball], [TotalConstraint3D(floor)], time_of_contact_diff=True)
+    for _ in range(12):
+        w.step(fixed_dt=True)
+    k = len(g["traj_t"]) - 1
+    for i, b in enumerate((floor, box, ball)):
+        assert np.abs(b.p.detach().cpu().numpy() - g["traj_p"][k][i]).max() < 1e-7
+    loss = sum((b.pos ** 2).sum() for b in (floor, box, ball))
+    loss.backward()
+    assert np.abs(d.grad.numpy() - g["grad_0"]).max() < 1e-5 * np.abs(g["grad_0"]).max(), (d.grad, g["grad_0"])
+    assert abs(float(r.grad) - float(g["grad_1"])) < 1e-5 * abs(float(g["grad_1"])), (r.grad, g["grad_1"])
