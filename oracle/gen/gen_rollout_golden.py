@@ -71,14 +71,14 @@ def describe(bodies, g=10.0, store_mesh=True):
     return d
 
 
-def branch_b_grads(make, nsteps, toc, jitter=1e-13):
+def branch_b_grads(make, nsteps, toc, jitter=1e-13, **world_kw):
     """The reference's gradient is bimodal on flat-on-flat contacts: `stable_mask = |lap2| < |lap1|`
     (contacts.py:198) compares two rounding-noise Laplacians, so which body's normal carries the gradient
     is decided by the last bit.  A 1e-13 nudge of one initial velocity samples the other branch."""
     bodies, joints, params = make()
     with torch.no_grad():
         bodies[-1].v[3] += jitter
-    w = World3D(bodies, joints, time_of_contact_diff=toc)
+    w = World3D(bodies, joints, time_of_contact_diff=toc, **world_kw)
     for _ in range(nsteps):
         w.step(fixed_dt=True)
     loss = sum((b.pos ** 2).sum() for b in bodies)
@@ -86,10 +86,10 @@ def branch_b_grads(make, nsteps, toc, jitter=1e-13):
             for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True))]
 
 
-def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True):
+def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
     bodies, joints, params = make()
     d = describe(bodies, store_mesh=store_mesh)
-    w = World3D(bodies, joints, time_of_contact_diff=toc)
+    w = World3D(bodies, joints, time_of_contact_diff=toc, **world_kw)
     d["dt"], d["eps"], d["tol"], d["fric_dirs"], d["toc_diff"] = w.dt, w.eps, w.tol, w.fric_dirs, int(toc)
     d["fixed"] = np.array(fixed, np.int32)
     b0, g0 = contacts_arrays(w.contacts)
@@ -114,7 +114,7 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True):
         for i, (p, g) in enumerate(zip(params, grads)):
             d["param_%d" % i] = p.detach().numpy()
             d["grad_%d" % i] = np.zeros_like(p.detach().numpy()) if g is None else g.numpy()
-        for i, gb in enumerate(branch_b_grads(make, nsteps, toc)):
+        for i, gb in enumerate(branch_b_grads(make, nsteps, toc, **world_kw)):
             d["gradB_%d" % i] = gb
     d["loss"] = float(loss)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
@@ -138,6 +138,7 @@ CASES = {
     # cases that came out of random comparisons against the reference (tools/dbg_fuzz.py): each one exposed a difference
     # in the thinning stage's hull (coincident points, a mid-edge start vertex, Qhull's merge tolerance) or exercises
     # bookkeeping no other golden has (pinned body not first, no_contact pairs, sphere against sphere)
+    "rollout_boxdrop_fd4": (lambda: scenes.box_drop(seed=7), dict(nsteps=12, fric_dirs=4)),      # World3D(fric_dirs=4)
     "rollout_two_spheres": (lambda: scenes.two_spheres(), dict(nsteps=12)),
     "rollout_sphere_on_box": (lambda: scenes.sphere_on_box(), dict(nsteps=12)),
     "rollout_floor_last": (lambda: scenes.floor_last(), dict(nsteps=20, fixed=(1,))),

@@ -113,10 +113,10 @@ def test_config3_scene_gradients_against_reference_autograd():
 
 
 @pytest.mark.parametrize("name,nsteps", [("rollout_two_spheres", 12), ("rollout_sphere_on_box", 12), ("rollout_floor_last", 20),
-                                         ("rollout_no_contact", 6), ("rollout_sphere_roll", 40)])
+                                         ("rollout_no_contact", 6), ("rollout_sphere_roll", 40), ("rollout_boxdrop_fd4", 12)])
 def test_cases_found_by_random_comparison(name, nsteps):
     """Scenes kept from random comparisons against the reference (tools/dbg_fuzz.py): sphere against sphere, three
-    bodies, a pinned body that is not body 0, a no_contact pair, a rolling sphere with coincident contact points.  Held:
+    bodies, a pinned body that is not body 0, a no_contact pair, a rolling sphere with coincident contact points, four friction directions.  Held:
     the number of sub-steps, the contact COUNT of every sub-step (the thinning stage must pick Qhull's vertices), poses
     to 1e-9 and d sum|pos_T|^2 / d parameters to 1e-5 (gradients below 1e-9 in magnitude are not compared)."""
     g, E = make(name, 2, max_sub=96)
