@@ -92,6 +92,7 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
     w = World3D(bodies, joints, time_of_contact_diff=toc, **world_kw)
     d["dt"], d["eps"], d["tol"], d["fric_dirs"], d["toc_diff"] = w.dt, w.eps, w.tol, w.fric_dirs, int(toc)
     d["fixed"] = np.array(fixed, np.int32)
+    d["strict_no_pen"] = int(w.strict_no_pen)
     b0, g0 = contacts_arrays(w.contacts)
     d["init_body"], d["init_geom"] = b0, g0
     for _ in range(nsteps):

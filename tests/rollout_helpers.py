@@ -35,6 +35,8 @@ def pair_multiset(body, n):
 def engine_kwargs(g, **over):
     kw = dict(dt=float(g["dt"]), eps=float(g["eps"]), tol=float(g["tol"]), fric_dirs=int(g["fric_dirs"]),
               toc_diff=bool(g["toc_diff"]), maxc=64, max_cand=1024, max_pc=32)
+    if "strict_no_pen" in g:
+        kw["strict_no_pen"] = bool(g["strict_no_pen"])
     kw.update(over)
     return kw
 
