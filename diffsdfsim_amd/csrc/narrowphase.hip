@@ -431,8 +431,48 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         G::sync();
         const int mu = S.wave_tot[0];
         G::sync();
-        if (mu > HULL3_MAX) {  // beyond the brute-force limit: keep every distinct point (superset of the hull)
-            for (int k = tid; k < m; k += G::BT) P.setf(k, P.getf(k) == 3 ? 0 : 1);
+        if (mu > HULL3_MAX) {
+            // Beyond the brute-force limit: a superset of the hull's vertices -- every distinct point, except (full
+            // variant, up to 512 points) those that lie on the segment between two other points.  That is what a curved
+            // level-set surface in line contact needs (a cylinder lying on the floor: rows of collinear contact points
+            // along its length, of which only the two ends of a row are vertices).
+#if DSS_ALL_SHAPES
+            // the distinct points, listed once (workgroup: in the scan's LDS words, free by now; a wavefront's cluster is
+            // small enough to walk with its duplicates)
+            constexpr int UCAP = G::BT == 64 ? 1 : 512;
+            const bool listed = G::BT != 64 && mu <= UCAP;
+            if (listed && tid == 0) { int u = 0; for (int k = 0; k < m; ++k) if (P.getf(k) != 3) S.woff[u++] = k; }
+            G::sync();
+            const bool thin = listed || (G::BT == 64 && mu <= 512);
+            const int nu = listed ? mu : m;
+#else
+            const bool thin = false, listed = false;
+            const int nu = m;
+#endif
+            for (int q = tid; q < m; q += G::BT) {
+                int keep = P.getf(q) != 3;
+                if (keep && thin) {
+                    const double qx = P.hp(q, 0), qy = P.hp(q, 1), qz = P.hp(q, 2);
+                    for (int ia = 0; ia < nu && keep; ++ia) {
+                        const int a = listed ? S.woff[ia] : ia;
+                        if (a == q || P.getf(a) == 3) continue;
+                        const double ax = P.hp(a, 0) - qx, ay = P.hp(a, 1) - qy, az = P.hp(a, 2) - qz;
+                        for (int ib = ia + 1; ib < nu; ++ib) {
+                            const int b = listed ? S.woff[ib] : ib;
+                            if (b == q || P.getf(b) == 3) continue;
+                            const double bx = P.hp(b, 0) - qx, by = P.hp(b, 1) - qy, bz = P.hp(b, 2) - qz;
+                            if (!(ax * bx + ay * by + az * bz < 0.0)) continue;          // q is not between a and b
+                            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+                            const double ex = bx - ax, ey = by - ay, ez = bz - az;
+                            // distance of q from the line a-b, squared: |a x b|^2 / |b - a|^2
+                            if (cx * cx + cy * cy + cz * cz <= tolf * tolf * (ex * ex + ey * ey + ez * ez)) { keep = 0; break; }
+                        }
+                    }
+                }
+                if (P.getf(q) != 3) P.setf(q, keep ? 1 : 4);      // other threads only ask whether a flag is 3
+            }
+            G::sync();
+            for (int k = tid; k < m; k += G::BT) { const int f = P.getf(k); P.setf(k, f == 1 ? 1 : 0); }
             G::sync();
             return;
         }

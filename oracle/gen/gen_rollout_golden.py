@@ -153,6 +153,8 @@ CASES = {
     # the same scene with d sum|pos_T|^2 / d dims: through the SDF, through the level-set mesh (MeshSDF backward) and
     # through the inertia integrated over that mesh
     "rollout_rounded_grad": (lambda: scenes.rounded_drop("rounded", requires_grad=True), dict(nsteps=10, store_mesh=False)),
+    "rollout_levelset_sphere": (lambda: scenes.levelset_sphere(), dict(nsteps=12, store_mesh=False)),
+    "rollout_levelset_cylinder": (lambda: scenes.levelset_cylinder(), dict(nsteps=8, store_mesh=False)),
     "rollout_levelset_box": (lambda: scenes.levelset_box(), dict(nsteps=3, store_mesh=False)),
     "rollout_brick": (lambda: scenes.rounded_drop("brick"), dict(nsteps=10, store_mesh=False)),
 }

@@ -202,3 +202,23 @@ def levelset_box(mu=0.4, rest=0.1, requires_grad=False):
     b = SDFBox([0.0, 0.2 + 5e-4, 0.0], d, vel=[0, 0, 0, 0.4, 0, 0.1], restitution=rest, fric_coeff=mu)
     b.add_force(Gravity3D())
     return [f, b], [TotalConstraint3D(f)], ([d] if requires_grad else [])
+
+
+def levelset_sphere(requires_grad=True):
+    """A sphere with the reference's default (level-set) mesh and integrated inertia dropped with spin: gradient w.r.t. its
+    radius through the SDF, the mesh scale and the inertia."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(); r = _T(0.3, requires_grad)
+    s = SDFSphere([0.0, 0.45, 0.0], r, vel=[0, 0, 1.0, 0.5, -0.5, 0], restitution=0.3, fric_coeff=0.4)
+    s.add_force(Gravity3D())
+    return [f, s], [TotalConstraint3D(f)], [r]
+
+
+def levelset_cylinder(requires_grad=True):
+    """A level-set cylinder lying on the floor and rolling: line contact on a curved level-set surface (one normal cluster
+    of ~850 contact points, ~340 distinct, in rows along the length of which the hull keeps the ends)."""
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(); r, h = _T(0.25, requires_grad), _T(0.6, requires_grad)
+    c = SDFCylinder([0.0, 0.2505, 0.0], r, h, vel=[0, 0, 1.0, 0.5, 0, 0], restitution=0.1, fric_coeff=0.3)
+    c.add_force(Gravity3D())
+    return [f, c], [TotalConstraint3D(f)], [r, h]

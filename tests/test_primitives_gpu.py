@@ -179,3 +179,36 @@ def test_box_with_the_reference_default_mesh_resting_flat_matches_reference():
         assert int(tnc[j, 0]) == int(g["traj_nc"][j - 1])
     for s in (0, 1):
         R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
+
+
+@pytest.mark.parametrize("name", ["rollout_levelset_sphere", "rollout_levelset_cylinder"])
+def test_default_mesh_sphere_and_cylinder_trajectory_and_gradient(name):
+    """SDFSphere / SDFCylinder with the reference's defaults (custom_mesh = custom_inertia = False) through the class API:
+    the device mesher reproduces the mesh the reference simulated (sizes), the trajectory follows to 1e-9 and the gradient
+    w.r.t. radius (/ height) -- through the SDF, the level-set vertices and the integrated inertia -- to 1e-6.  The lying
+    cylinder is in line contact on a curved level-set surface: its ~340 distinct contact points of one normal cluster
+    are thinned to the ends of their rows, as Qhull's 3-D hull does."""
+    from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, World3D
+    g = R.load_rollout(name)
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True, restitution=0.3, fric_coeff=0.4)
+    T = lambda x: torch.tensor(x, dtype=torch.double, requires_grad=True)
+    if name.endswith("sphere"):
+        prm = [T(0.3)]
+        b = SDFSphere([0.0, 0.45, 0.0], prm[0], vel=[0, 0, 1.0, 0.5, -0.5, 0], restitution=0.3, fric_coeff=0.4, custom_mesh=False, custom_inertia=False)
+        n = 12
+    else:
+        prm = [T(0.25), T(0.6)]
+        b = SDFCylinder([0.0, 0.2505, 0.0], prm[0], prm[1], vel=[0, 0, 1.0, 0.5, 0, 0], restitution=0.1, fric_coeff=0.3, custom_mesh=False, custom_inertia=False)
+        n = 8
+    b.add_force(Gravity3D())
+    assert (len(b.verts), len(b.faces)) == tuple(g["meshsize_1"])
+    w = World3D([floor, b], [TotalConstraint3D(floor)])
+    assert len(w.contacts) == len(g["init_body"])
+    for _ in range(n):
+        w.step(fixed_dt=True)
+    assert np.abs(b.p.detach().cpu().numpy() - g["traj_p"][-1][1]).max() < 1e-9
+    loss = (floor.p[4:] ** 2).sum() + (b.p[4:] ** 2).sum()
+    loss.backward()
+    for i, p in enumerate(prm):
+        want = float(g["grad_%d" % i])
+        assert abs(float(p.grad) - want) < 1e-6 * abs(want), (i, float(p.grad), want)
