@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "tmp_*.npz"))):
     if any(k.startswith("meshsize_") for k in g):
         import test_primitives_gpu as T
         lsm = T.level_set_mesh(g)
-    kw = dict(max_sub=256, maxc=160, max_pc=128, max_cand=32768) if lsm else dict(max_sub=256, maxc=160, max_pc=32)
+    kw = dict(max_sub=256, maxc=256, max_pc=256, max_cand=32768) if lsm else dict(max_sub=256, maxc=160, max_pc=32)
     E = BatchEngine(R.spec_from_golden(g, 1, lsm), **R.engine_kwargs(g, **kw))
     for _ in range(nsteps):
         E.step()
