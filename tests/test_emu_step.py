@@ -49,3 +49,20 @@ def test_single_body_contact_free_branch_matches_reference():
         E.step()
         assert np.abs(E.get("pose")[0, 0] - g["traj_p"][k]).max() < 1e-10 and np.abs(E.get("vel")[0, 0] - g["traj_v"][k]).max() < 1e-10
     assert (E.get("nc") == 0).all()
+
+
+@pytest.mark.parametrize("name,nsteps", [("rollout_sphere", 24), ("rollout_boxdrop", 12)])
+def test_full_kernel_variants_agree_with_the_lean_ones(name, nsteps):
+    """The same goldens through the full variants of the narrow phase and the contact adjoint (every primitive, level-set
+    hull handling; selected with spec['full_kernels']): bit-identical state and gradients to the lean variants."""
+    g = R.load_rollout(name)
+    out = []
+    for full in (False, True):
+        spec = R.spec_from_golden(g)
+        spec["full_kernels"] = full
+        E = BatchEngine(spec, backend=emu.EmuBackend(), max_sub=64, **R.engine_kwargs(g))
+        assert int(E.W.shape_rare) == int(full)
+        R.rollout_and_sweep(E, nsteps)
+        out.append((E.get("pose").copy(), E.get("vel").copy(), E.get("nsub").copy(), E.be.to_numpy(E.adj["g_prm"]).copy()))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
