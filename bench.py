@@ -76,6 +76,30 @@ def cpu_baseline(E, n_sample, threads):
     return dt / len(pick), len(pick), nineq_max
 
 
+def self_launch(n):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same variables
+    torch.distributed.run sets), same argv.  With fewer visible GPUs than ranks the ranks share devices and the
+    collectives go through gloo (a rehearsal of the same code path, flagged in the JSON line)."""
+    import socket
+    import subprocess
+    import torch   # importing torch and counting devices does not initialise the GPU
+    ndev = torch.cuda.device_count()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        if ndev < n:
+            env.setdefault("DSS_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +112,11 @@ def main():
     ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N children, one rank per GPU, started BEFORE anything in
+        # this process touches the GPU (no exec of an initialised process); rank 0's JSON line is the children's stdout
+        sys.exit(self_launch(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -99,6 +128,14 @@ def main():
         # several ranks sharing one GPU (collectives then go through host copies)
         backend = os.environ.get("DSS_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if os.environ.get("DSS_BENCH_DRYRUN"):   # launcher + rendezvous check without a GPU (tests/test_bench_launcher.py)
+            mine = torch.tensor([rank], dtype=torch.int64)
+            got = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            if rank == 0:
+                print(json.dumps({"dryrun": True, "n_gpus": world, "ranks": [int(g) for g in got], "backend": backend}))
+            dist.destroy_process_group()
+            return
     else:
         dist = None
         backend = None
@@ -180,8 +217,10 @@ def main():
     loss_adjoint()
     E.adj["lo_slot"].copy_(lo)
     E.backward_sweep(att)
-    final = E.arr["pose"].clone()
-    if dist is not None:   # "final trivial gather" of the shard results
+    # "final trivial gather" of the shard results: final poses and the per-scene parameter gradients
+    final = torch.cat([E.arr["pose"].reshape(B, -1), E.adj["g_prm"].reshape(B, -1), E.adj["g_mass"].reshape(B, -1),
+                       E.adj["g_fric"].reshape(B, -1)], dim=1)
+    if dist is not None:
         fin = final.to(cdev)
         out = [torch.empty_like(fin) for _ in range(world)]
         dist.all_gather(out, fin)
@@ -244,7 +283,8 @@ def main():
                    "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()),
                    "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
-                   "parallelism": "scene-sharded x%d, no collective in step" % world},
+                   "parallelism": "scene-sharded x%d, no collective in step; one all_gather (%s) of final poses + per-scene "
+                                  "gradients; %d physical device(s)" % (world, backend or "none", torch.cuda.device_count())},
         "roofline": dominant, "roofline_second_kernel": other,
     }
     if not args.no_cpu:

@@ -142,6 +142,9 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
         toc = __ballot(toc) != 0ull;
         // tape record of the accepted sub-step
         const int slot = W.nsub[sc];
+        // the tape is full: the sub-step cannot be recorded, a reverse sweep over it would read past the tape.  A capacity
+        // error like the others (sticky, the host raises): max_sub has to be raised.
+        if (W.tp_pose && slot >= W.max_sub && lane == 0) { atomicOr(W.overflow + sc, 16); atomicOr(W.n_active, DSS_N_ACTIVE_OVERFLOW); }
         if (W.tp_pose && slot < W.max_sub) {
             const size_t rec = (size_t)slot * W.B + sc;
             if (lane < nb) {

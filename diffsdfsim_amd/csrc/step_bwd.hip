@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
 {
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
     const int k = A.cur_slot[sc];
-    const int act = (k >= 0 && k >= A.lo_slot[sc] && k < W.nsub[sc]);
+    const int act = (k >= 0 && k >= A.lo_slot[sc] && k < W.nsub[sc] && k < W.max_sub);   // (a slot beyond the tape was never recorded)
     // slot -1 = the contacts found at construction (World.__init__, world.py:96): only their geometry
     // adjoint is left to push onto the initial pose and the shape parameters
     const int init = (k == -1 && A.lo_slot[sc] <= -1 && W.nsub[sc] > 0);
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
     if (!act && !init) return;
     SlotView v;
     double *a_pose = A.a_pose + (size_t)sc * nb * 7, *a_vel = A.a_vel + (size_t)sc * nb * 6;
-    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * 20 * MX;
+    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * DSS_CSCR_ROWS * MX;
     if (init) {
         const size_t r0 = (size_t)sc;   // tape slot 0
         v.pose_n = W.tp_pose + r0 * nb * 7;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
     if (ev) {
         const double dtbar_h = dt_int + A.a_last_dt[sc];
         const double h = v.dt;
-        double dDdh[3] = {0, 0, 0};   // up to 3 contacts per lane (maxc <= 192)
+        double dDdh[3] = {0, 0, 0};
         int q = 0;
         double den = 0.0;
         auto fill = [&](int c, double *in) {
@@ -288,25 +288,30 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
             }
             return true;
         };
-        for (int c = lane; c < v.nc_n; c += 64, ++q) {
-            if (!is_toc(c)) continue;
+        auto dD_dh = [&](int c) -> double {
+            if (!is_toc(c)) return 0.0;
             double in[43];
             fill(c, in);
             typedef Dual<1> D;
             D di[43];
             for (int i = 0; i < 43; ++i) di[i] = D(in[i]);
             di[0].d[0] = 1.0;
-            double g = toc_D(di).d[0];
-            if (g < 1e-6 / h) g = 0.0;          // only motion into collision (world.py:203; Defaults.TOL = 1e-6)
-            if (q < 3) dDdh[q] = g;
+            const double g = toc_D(di).d[0];
+            return g < 1e-6 / h ? 0.0 : g;      // only motion into collision (world.py:203; Defaults.TOL = 1e-6)
+        };
+        for (int c = lane; c < v.nc_n; c += 64, ++q) {
+            const double g = dD_dh(c);
+            if (q < 3) dDdh[q] = g;             // the first three contacts of a lane are cached, later ones recomputed below
             den += g * g;
         }
         den = wave_sum(den);
         q = 0;
         for (int c = lane; c < v.nc_n; c += 64, ++q) {
             for (int r = 20; r < 53; ++r) cs[(size_t)r * MX + c] = 0.0;
-            if (!(den > 1e-5) || q >= 3 || dDdh[q] == 0.0) continue;
-            const double wgt = -(dDdh[q] / den) * dtbar_h;
+            if (!(den > 1e-5)) continue;
+            const double gq = q < 3 ? dDdh[q] : dD_dh(c);
+            if (gq == 0.0) continue;
+            const double wgt = -(gq / den) * dtbar_h;
             double in[43], outg[44];
             fill(c, in);
             for (int grp = 0; grp < 11; ++grp) {
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
     view_slot(W, sc, k, v);
     const int ND = W.fric_dirs / 2, NF = 3 * (1 + ND) + 8, o = 3 * (1 + ND);
     double *a_pose = A.a_pose + (size_t)sc * nb * 7, *a_vel = A.a_vel + (size_t)sc * nb * 6;
-    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * 20 * MX;
+    double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * DSS_CSCR_ROWS * MX;
     const double *dcop = A.dcop + (size_t)sc * NF * MX, *dM = A.dMblk + (size_t)sc * nb * 36, *du = A.dpvec + (size_t)sc * 6 * nb;
 
     // contacts of sub-step k: adjoint of (dirs, p1, p2, mu, h_n) -> geometry, friction, restitution, velocities

@@ -17,8 +17,8 @@ class Defaults3D:
     DTYPE = torch.double
     DEVICE = torch.device("cuda:0")
     POST_STABILIZATION = False
-    CUSTOM_MESH = True       # analytic meshes; marching cubes is SURVEY.md §8f N1
-    CUSTOM_INERTIA = True
+    CUSTOM_MESH = False      # as sdf_physics/physics3d/utils.py:56-57: level-set (marching cubes) mesh and mesh inertia unless
+    CUSTOM_INERTIA = False   # the caller asks for the analytic ones
 
 
 def get_tensor(x, base_tensor=None, **kw):

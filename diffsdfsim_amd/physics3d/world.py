@@ -40,6 +40,7 @@ class _StepFn(torch.autograd.Function):
         nsub0 = E.arr["nsub"].clone()
         att = E.step() if fixed_dt else E.step_once()
         ctx.world, ctx.nsub0, ctx.att = world, nsub0, att
+        ctx.nsub1 = E.arr["nsub"].clone()      # tape slots [nsub0, nsub1) belong to this node
         ctx.index = world._n_nodes
         world._n_nodes += 1
         out_pose, out_vel = E.arr["pose"].clone(), E.arr["vel"].clone()
@@ -53,7 +54,12 @@ class _StepFn(torch.autograd.Function):
         if ctx.index == w._n_nodes - 1 or w._bw_next != ctx.index:   # newest node: start a fresh reverse sweep
             adj["a_geom"].zero_()
             adj["a_last_dt"].zero_()
-            adj["cur_slot"].copy_(E.arr["nsub"] - 1)
+            # the sweep starts at THIS node's last tape slot: the loss may depend on an intermediate step only, with the
+            # world stepped further before backward() (the reference's autograd handles that; later slots are not this
+            # node's).  A tape that was rolled back and overwritten since (undo_step + new steps) cannot be differentiated.
+            if bool((E.arr["nsub"] < ctx.nsub1).any()):
+                raise RuntimeError("backward through a step whose tape slots were released by undo_step()")
+            adj["cur_slot"].copy_(ctx.nsub1 - 1)
         w._bw_next = ctx.index - 1
         for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm", "g_verts"):
             adj[k].zero_()

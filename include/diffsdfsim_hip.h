@@ -171,7 +171,7 @@ typedef struct DssWorld {
     int *n_pairs;            /* [6]: workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
                                 work cursors, deferred-list length and cursor */
     int *invalid;            /* [B] penetration > tol found in this attempt */
-    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc */
+    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc, 16 max_sub (tape slots) */
     int *pc_count;           /* [B][npairs] */
     int *pc_stats;           /* [B][npairs][2] work done for the pair: face runs tested, candidate faces (bench accounting) */
     int *pc_face;            /* [B][npairs][max_pc] */

@@ -137,22 +137,39 @@ def test_cases_found_by_random_comparison(name, nsteps):
 
 
 def test_scenes_of_a_batch_do_not_influence_each_other():
-    """Six different sphere drops (different radii, heights, speeds: impacts, dt halving and time-of-contact events
+    """64 different sphere drops (different radii, heights, speeds: impacts, dt halving and time-of-contact events
     fall in different attempts) stepped as one batch and one by one: poses, velocities, sub-step counts and gradients must
-    be bit-identical -- the lock-step retry loop and the work lists of the persistent narrow phase couple nothing."""
+    be bit-identical -- the lock-step retry loop, the work lists of the persistent narrow phase and the per-scene scratch
+    of the reverse sweep (DssAdjoint.cscr: rows of a scene must not reach into its neighbours') couple nothing."""
     from diffsdfsim_amd import scenes
     from diffsdfsim_amd.engine import BatchEngine
-    spec = scenes.sphere_drop(6, seed=5, floor_dims=(4.0, 1.0, 4.0))
+    nS = 64
+    spec = scenes.sphere_drop(nS, seed=5, floor_dims=(4.0, 1.0, 4.0))
     T = 30
 
     def run(sp):
         E = BatchEngine(sp, max_sub=4 * T + 16, maxc=64)
         R.rollout_and_sweep(E, T)
-        return E.get("pose").copy(), E.get("vel").copy(), E.get("nsub").copy(), E.be.to_numpy(E.adj["g_prm"]).copy()
+        flags = E.get("tp_flags")
+        return (E.get("pose").copy(), E.get("vel").copy(), E.get("nsub").copy(), E.be.to_numpy(E.adj["g_prm"]).copy(),
+                E.be.to_numpy(E.adj["g_mass"]).copy(), (flags & 1).sum(axis=0))
 
-    P, V, N, G = run(spec)
-    assert len(set(N.tolist())) > 1, "the scenes were meant to take different numbers of sub-steps"
-    for s in range(6):
-        one = {k: (v[s:s + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (6,) else v) for k, v in spec.items()}
-        p, v, n, g = run(one)
-        assert n[0] == N[s] and np.array_equal(p[0], P[s]) and np.array_equal(v[0], V[s]) and np.array_equal(g[0], G[s]), s
+    P, V, N, G, GM, toc = run(spec)
+    assert len(set(N.tolist())) > 3, "the scenes were meant to take different numbers of sub-steps"
+    assert (toc > 0).sum() >= nS // 2, "most scenes were meant to go through a time-of-contact event"
+    for s in range(nS):
+        one = {k: (v[s:s + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (nS,) else v) for k, v in spec.items()}
+        p, v, n, g, gm, _ = run(one)
+        assert n[0] == N[s] and np.array_equal(p[0], P[s]) and np.array_equal(v[0], V[s]), s
+        assert np.array_equal(g[0], G[s]) and np.array_equal(gm[0], GM[s]), (s, g[0], G[s])
+
+
+def test_tape_overflow_is_a_capacity_error():
+    """More accepted sub-steps than tape slots (max_sub): the engine raises instead of dropping records that a reverse
+    sweep would then read past the tape."""
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.engine import BatchEngine
+    E = BatchEngine(scenes.sphere_drop(3, seed=5, floor_dims=(4.0, 1.0, 4.0)), max_sub=4, maxc=64)
+    with pytest.raises(RuntimeError, match="max_sub"):
+        for _ in range(8):
+            E.step()

@@ -7,13 +7,16 @@ import rollout_helpers as R
 
 pytestmark = pytest.mark.gpu
 
+# the goldens were recorded with the reference's analytic meshes / inertias (its defaults are the level-set ones)
+CUSTOM = dict(custom_mesh=True, custom_inertia=True)
+
 
 def build_sphere_world(g, toc):
     from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, SDFSphere, TotalConstraint3D, World3D
-    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=float(g["restitution"][0]), fric_coeff=float(g["fric"][0]))
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=float(g["restitution"][0]), fric_coeff=float(g["fric"][0]), **CUSTOM)
     rad = torch.tensor(float(g["param_0"]), dtype=torch.float64, requires_grad=True)
     ball = SDFSphere(g["pose0"][1, 4:].tolist(), rad, vel=g["vel0"][1].tolist(), restitution=float(g["restitution"][1]),
-                     fric_coeff=float(g["fric"][1]))
+                     fric_coeff=float(g["fric"][1]), **CUSTOM)
     ball.add_force(Gravity3D())
     w = World3D([floor, ball], [TotalConstraint3D(floor)], time_of_contact_diff=toc)
     return w, floor, ball, rad
@@ -147,11 +150,11 @@ def test_world3d_three_bodies_gradients_wrt_box_dims_and_sphere_radius():
     (torch), against the reference's autograd."""
     from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, SDFSphere, TotalConstraint3D, World3D
     g = R.load_rollout("rollout_sphere_on_box")
-    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=0.3, fric_coeff=0.4)
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], restitution=0.3, fric_coeff=0.4, **CUSTOM)
     d = torch.tensor(g["param_0"], dtype=torch.float64, requires_grad=True)
     r = torch.tensor(float(g["param_1"]), dtype=torch.float64, requires_grad=True)
-    box = SDFBox(g["pose0"][1, 4:].tolist(), d, vel=g["vel0"][1].tolist(), restitution=0.2, fric_coeff=0.4)
-    ball = SDFSphere(g["pose0"][2, 4:].tolist(), r, vel=g["vel0"][2].tolist(), restitution=0.2, fric_coeff=0.4)
+    box = SDFBox(g["pose0"][1, 4:].tolist(), d, vel=g["vel0"][1].tolist(), restitution=0.2, fric_coeff=0.4, **CUSTOM)
+    ball = SDFSphere(g["pose0"][2, 4:].tolist(), r, vel=g["vel0"][2].tolist(), restitution=0.2, fric_coeff=0.4, **CUSTOM)
     for b in (box, ball):
         b.add_force(Gravity3D())
     w = World3D([floor, box, ball], [TotalConstraint3D(floor)], time_of_contact_diff=True)
@@ -164,3 +167,22 @@ def test_world3d_three_bodies_gradients_wrt_box_dims_and_sphere_radius():
     loss.backward()
     assert np.abs(d.grad.numpy() - g["grad_0"]).max() < 1e-5 * np.abs(g["grad_0"]).max(), (d.grad, g["grad_0"])
     assert abs(float(r.grad) - float(g["grad_1"])) < 1e-5 * abs(float(g["grad_1"])), (r.grad, g["grad_1"])
+
+
+def test_loss_on_an_intermediate_step_with_the_world_stepped_further():
+    """d |pos_k|^2 / d rad for k < T, the world having been stepped on to T before backward(): the reverse sweep starts at
+    the tape slot of step k, not at the engine's newest one.  Must equal the gradient of a world stepped to k only."""
+    g = R.load_rollout("rollout_sphere")
+
+    def grad_at(k, T):
+        w, floor, ball, rad = build_sphere_world(g, toc=True)
+        loss = None
+        for i in range(T):
+            w.step(fixed_dt=True)
+            if i + 1 == k:
+                loss = (ball.pos ** 2).sum()
+        loss.backward()
+        return float(rad.grad)
+
+    a, b = grad_at(20, 20), grad_at(20, 24)
+    assert a != 0.0 and a == b, (a, b)
