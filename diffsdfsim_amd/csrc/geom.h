@@ -287,7 +287,7 @@ inline namespace shapes_all {
 #else
 inline namespace shapes_lean {
 #endif
-enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2, SHAPE_BOX_ROUNDED = 3, SHAPE_BRICK = 4, SHAPE_BOWL = 5 };
+enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2, SHAPE_BOX_ROUNDED = 3, SHAPE_BRICK = 4, SHAPE_BOWL = 5, SHAPE_IGR = 6 };
 
 template <class T> struct Shape {
     int type;
@@ -327,6 +327,9 @@ template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int t
     } else if (type == SHAPE_BOWL) {       // bodies.py:1013-1027: scale = (r + d) * 1.3333, params r/scale, d/scale
         s.scale = (prm[0] + prm[1]) * 1.3333;
         s.hd[0] = prm[0] / s.scale; s.hd[1] = prm[1] / s.scale; s.hd[2] = T(0.0);
+    } else if (type == SHAPE_IGR) {        // SDF3D with a network (bodies.py:627-651): prm = latent code, aux = the given scale
+        s.scale = T(aux);
+        for (int i = 0; i < 3; ++i) s.hd[i] = T(0.0);
 #endif
     } else {
         s.scale = prm[0] * 1.5;
@@ -467,6 +470,13 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
             normalize(go, g1);
             normalize(g1, g);
         }
+#endif
+#if DSS_ALL_SHAPES
+    } else if (s.type == SHAPE_IGR) {
+        // a network is never evaluated lane by lane: its queries go through the matrix-core rounds (narrowphase_igr.hip,
+        // igr_mlp.hip).  Reaching this branch is a bug; make it loud.
+        phi = T(NAN);
+        if (want_grad) for (int i = 0; i < 3; ++i) g[i] = T(NAN);
 #endif
     } else {
         const T n = norm3(p);

@@ -6,17 +6,21 @@
 // query_sdfs needs phi AND d phi/d xyz (the reference gets the latter from autograd, bodies.py:730-745).
 //
 // This is the one dense-GEMM shaped piece of the hot path, so it runs on the matrix cores:
-//   * forward-mode: every point carries (h, dh/dx, dh/dy, dh/dz); the 16-row MFMA tile holds 4 points x 4
-//     quantities, ordered row = 4*quantity + point.  With v_mfma_f64_16x16x4 a lane's four accumulator registers
-//     are rows q, q+4, q+8, q+12 of one column (q = lane>>4): exactly (value, dx, dy, dz) of ONE point and ONE
+//   * MODE_XYZ / MODE_LATENT, forward-mode: every point carries (h, three tangents); the 16-row MFMA tile holds 4 points
+//     x 4 quantities, ordered row = 4*quantity + point.  With v_mfma_f64_16x16x4 a lane's four accumulator registers
+//     are rows q, q+4, q+8, q+12 of one column (q = lane>>4): exactly (value, t0, t1, t2) of ONE point and ONE
 //     neuron, so bias + softplus + sigmoid-scaling of the tangents is lane-local.  No activations are kept for a
 //     backward sweep and no transposed weights are needed.
-//   * a workgroup of NW waves owns 4*NG points; wave w computes neuron tiles [w*8/NW, (w+1)*8/NW) for all of them
-//     (NG x 8/NW accumulator tiles in AGPRs).  Activations of the current layer live in LDS ([16 NG rows][128+1]),
-//     weights stream from L2 in MFMA-fragment order (host-packed: one coalesced 512-B load per fragment, reused by
-//     all NG row groups), software-pipelined with the k-loop fully unrolled so ~60 fragment loads are in flight.
-//     Two workgroups' waves share a SIMD, so one's softplus epilogue (VALU) hides under the other's MFMAs.
-// Flops: 4 x 115 456 MAC per point = 0.92 MFLOP (fp64); matrix peak 256 CU x 128 flop/clk x 2.4 GHz = 78.6 TFLOP/s.
+//   * MODE_VALUE: the 16 rows of a tile are 16 points (values only: the candidate test of the narrow phase and the
+//     Laplacian probes need no gradient -- a quarter of the work).
+//   * a workgroup of NW waves owns NG row groups (4 NG points with tangents, 16 NG without); wave w computes neuron tiles
+//     [w*8/NW, (w+1)*8/NW) for all of them (NG x 8/NW accumulator tiles in AGPRs).  Activations of the current layer live
+//     in LDS ([16 NG rows][128+1]), weights stream from L2 in MFMA-fragment order (host-packed: one coalesced 512-B load
+//     per fragment, reused by all NG row groups), software-pipelined with the k-loop fully unrolled so ~60 fragment loads
+//     are in flight.  Two workgroups' waves share a SIMD, so one's softplus epilogue (VALU) hides under the other's MFMAs.
+//   * the grid is persistent over the tiles of a point list whose length may live in device memory (the query rounds of
+//     the neural narrow phase, narrowphase_igr.hip, fill such lists); every point names its latent code by an index.
+// Flops: 4 x 115 456 MAC per point = 0.92 MFLOP (fp64) with tangents; matrix peak 256 CU x 128 flop/clk x 2.4 GHz = 78.6 TFLOP/s.
 // Measured (128^3 grid, MI355X): 38.0 ms = 50.9 TFLOP/s = 65 % of peak.
 #include <math.h>
 
@@ -28,6 +32,7 @@ namespace {
 using namespace dss;
 
 constexpr int H = 128, NL = 9, DIN = 5, LDX = H + 1;
+enum { MODE_XYZ = DSS_IGR_XYZ, MODE_LATENT = DSS_IGR_LATENT, MODE_VALUE = DSS_IGR_VALUE };
 
 __device__ inline acc4 mfma(double a, double b, acc4 c) { return mfma_f64_16x16x4(a, b, c); }
 __device__ inline double &comp(acc4 &v, int i) { return acc_comp(v, i); }
@@ -42,120 +47,186 @@ __device__ inline void softplus100(double z, double &h, double &dh)
     dh = lin ? 1.0 : e / (1.0 + e);
 }
 
+struct Query {
+    const double *pts;       // [n][3] points in the network's unit frame
+    const int *lat_idx;      // [n] index of the point's latent code, or NULL = code 0
+    const double *latents;   // [.][lat_stride] latent codes (first two entries of a row)
+    int lat_stride;
+    const int *n_dev;        // length of the list in device memory, or NULL = n
+    int n;
+    double *sdf, *grad;      // [n], [n][3] (grad unused in MODE_VALUE)
+};
+
 // Wp: packed weights.  Per hidden->hidden layer (7 of them): [tile t 0..7][kstep 0..31][lane 0..63] = W[16t + (lane&15)][4ks + (lane>>4)]
-// NW waves per workgroup share the activations of NG groups of 4 points; wave w owns neuron tiles [w*8/NW, (w+1)*8/NW)
-template <int NW, int NG> __global__ void __launch_bounds__(64 * NW)
-igr_query_kernel(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
-                 const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, int wrt_latent)
+// NW waves per workgroup share the activations of NG row groups; wave w owns neuron tiles [w*8/NW, (w+1)*8/NW)
+template <int NW, int NG, int MODE> __global__ void __launch_bounds__(64 * NW)
+igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, const double *bh, const double *W8, const double *b8)
 {
-    DSS_DYN_LDS(double, X);   // [ROWS][LDX]: row = 4*quantity + point (+16 for the second group of 4 points)
-    constexpr int PTS = 4 * NG, ROWS = 4 * PTS, NT = 64 * NW, TPW = 8 / NW;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, base = blockIdx.x * PTS;
+    DSS_DYN_LDS(double, X);   // [ROWS][LDX]; with tangents row = 16 g + 4*quantity + point, without row = point
+    constexpr bool TAN = MODE != MODE_VALUE;
+    constexpr int PTS = (TAN ? 4 : 16) * NG, ROWS = 16 * NG, NT = 64 * NW, TPW = 8 / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 15, q = lane >> 4;
+    const int n = Q.n_dev ? *Q.n_dev : Q.n;
+    // row of (point p of the tile, quantity) and back
+    auto row_of = [](int p, int quant) { return TAN ? 16 * (p / 4) + 4 * quant + (p % 4) : p; };
 
-    // ---- layer 0 (K = 5) on the vector ALU: h0 = softplus(W0 [latent, xyz] + b0), tangents = sigma' * W0[:, 2+d]
-    for (int e = tid; e < PTS * H; e += NT) {
-        const int p = e / H, j = e % H, gp = base + p;
-        double in[DIN] = {latent[0], latent[1], 0.0, 0.0, 0.0};
-        if (gp < n) { in[2] = pts[3 * gp]; in[3] = pts[3 * gp + 1]; in[4] = pts[3 * gp + 2]; }
-        double z = b0[j];
-        for (int k = 0; k < DIN; ++k) z += W0[j * DIN + k] * in[k];
-        double h, dh;
-        softplus100(z, h, dh);
-        const int r0 = 16 * (p / 4) + (p % 4);
-        X[r0 * LDX + j] = h;
-        // tangent seeds: the three point coordinates (inputs 2..4), or the two latent coordinates (inputs 0, 1)
-        for (int d = 0; d < 3; ++d) X[(r0 + 4 * (d + 1)) * LDX + j] = wrt_latent ? (d < 2 ? dh * W0[j * DIN + d] : 0.0) : dh * W0[j * DIN + 2 + d];
-    }
-    __syncthreads();
+    for (int base = blockIdx.x * PTS; base < n; base += gridDim.x * PTS) {
+        // ---- layer 0 (K = 5) on the vector ALU: h0 = softplus(W0 [latent, xyz] + b0), tangents = sigma' * W0[:, seed]
+        for (int e = tid; e < PTS * H; e += NT) {
+            const int p = e / H, j = e % H, gp = base + p;
+            double in[DIN] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (gp < n) {
+                const double *lat = Q.latents + (size_t)(Q.lat_idx ? Q.lat_idx[gp] : 0) * Q.lat_stride;
+                in[0] = lat[0]; in[1] = lat[1];
+                in[2] = Q.pts[3 * gp]; in[3] = Q.pts[3 * gp + 1]; in[4] = Q.pts[3 * gp + 2];
+            }
+            double z = b0[j];
+            for (int k = 0; k < DIN; ++k) z += W0[j * DIN + k] * in[k];
+            double h, dh;
+            softplus100(z, h, dh);
+            X[row_of(p, 0) * LDX + j] = h;
+            if (TAN) {
+                // tangent seeds: the three point coordinates (inputs 2..4), or the two latent coordinates (inputs 0, 1)
+                for (int d = 0; d < 3; ++d)
+                    X[row_of(p, d + 1) * LDX + j] = MODE == MODE_LATENT ? (d < 2 ? dh * W0[j * DIN + d] : 0.0) : dh * W0[j * DIN + 2 + d];
+            }
+        }
+        __syncthreads();
 
-    for (int layer = 1; layer < NL - 1; ++layer) {
-        const double *Wl = Wp + (size_t)(layer - 1) * 8 * 32 * 64, *bl = bh + (size_t)(layer - 1) * H;
-        if (layer == 4) {
-            // skip connection: x = cat([h3 (123), input (5)]) / sqrt(2)   (value rows get the input, tangent rows its Jacobian)
-            for (int e = tid; e < ROWS * H; e += NT) {
-                const int r = e / H, j = e % H;
-                double v = X[r * LDX + j];
-                if (j >= H - DIN) {
-                    const int k = j - (H - DIN), quant = (r % 16) / 4, p = 4 * (r / 16) + (r % 4), gp = base + p;
-                    if (quant == 0) v = k < 2 ? latent[k] : (gp < n ? pts[3 * gp + k - 2] : 0.0);
-                    else v = ((wrt_latent ? k : k - 2) == quant - 1 && (wrt_latent ? k < 2 : k >= 2)) ? 1.0 : 0.0;
+        for (int layer = 1; layer < NL - 1; ++layer) {
+            const double *Wl = Wp + (size_t)(layer - 1) * 8 * 32 * 64, *bl = bh + (size_t)(layer - 1) * H;
+            if (layer == 4) {
+                // skip connection: x = cat([h3 (123), input (5)]) / sqrt(2)   (value rows get the input, tangent rows its Jacobian)
+                for (int e = tid; e < ROWS * H; e += NT) {
+                    const int r = e / H, j = e % H;
+                    double v = X[r * LDX + j];
+                    if (j >= H - DIN) {
+                        const int k = j - (H - DIN);
+                        const int quant = TAN ? (r % 16) / 4 : 0, p = TAN ? 4 * (r / 16) + (r % 4) : r, gp = base + p;
+                        if (quant == 0) {
+                            v = 0.0;
+                            if (gp < n) {
+                                const double *lat = Q.latents + (size_t)(Q.lat_idx ? Q.lat_idx[gp] : 0) * Q.lat_stride;
+                                v = k < 2 ? lat[k] : Q.pts[3 * gp + k - 2];
+                            }
+                        } else {
+                            const bool wl = MODE == MODE_LATENT;
+                            v = ((wl ? k : k - 2) == quant - 1 && (wl ? k < 2 : k >= 2)) ? 1.0 : 0.0;
+                        }
+                    }
+                    X[r * LDX + j] = v * 0.70710678118654752440;
                 }
-                X[r * LDX + j] = v * 0.70710678118654752440;
+                __syncthreads();
+            }
+            acc4 acc[NG][TPW];
+            for (int g = 0; g < NG; ++g)
+                for (int t = 0; t < TPW; ++t) { comp(acc[g][t], 0) = 0; comp(acc[g][t], 1) = 0; comp(acc[g][t], 2) = 0; comp(acc[g][t], 3) = 0; }
+            // software pipeline: the B fragments (and A) of k-step ks+1 are in flight while the MFMAs of ks issue
+            double bq[2][TPW], aq[2][NG], bias[TPW];
+            const double *Ww = Wl + (size_t)wv * TPW * 32 * 64;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) bias[t] = bl[16 * (wv * TPW + t) + col];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) bq[0][t] = Ww[(size_t)t * 32 * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) aq[0][g] = X[(16 * g + col) * LDX + q];
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < 32) {
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) bq[nxt][t] = Ww[((size_t)t * 32 + ks + 1) * 64 + lane];
+                    // A fragments: lane holds X[row = lane&15 (+16 g)][k = 4 ks + (lane>>4)]
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) aq[nxt][g] = X[(16 * g + col) * LDX + 4 * (ks + 1) + q];
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g][t] = mfma(aq[cur][g], bq[cur][t], acc[g][t]);
             }
             __syncthreads();
+            // epilogue.  With tangents this lane owns (value, t0, t1, t2) of point q (of group g) for neuron 16 t + col;
+            // without, the values of points q, q+4, q+8, q+12 of the group
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int j = 16 * (wv * TPW + t) + col;
+                    double h, dh;
+                    if (TAN) {
+                        softplus100(comp(acc[g][t], 0) + bias[t], h, dh);
+                        X[(16 * g + q) * LDX + j] = h;
+                        for (int d = 1; d < 4; ++d) X[(16 * g + 4 * d + q) * LDX + j] = dh * comp(acc[g][t], d);
+                    } else {
+                        for (int d = 0; d < 4; ++d) {
+                            softplus100(comp(acc[g][t], d) + bias[t], h, dh);
+                            X[(16 * g + 4 * d + q) * LDX + j] = h;
+                        }
+                    }
+                }
+            __syncthreads();
         }
-        acc4 acc[NG][TPW];
-        for (int g = 0; g < NG; ++g)
-            for (int t = 0; t < TPW; ++t) { comp(acc[g][t], 0) = 0; comp(acc[g][t], 1) = 0; comp(acc[g][t], 2) = 0; comp(acc[g][t], 3) = 0; }
-        // software pipeline: the B fragments (and A) of k-step ks+1 are in flight while the MFMAs of ks issue
-        double bq[2][TPW], aq[2][NG], bias[TPW];
-        const double *Ww = Wl + (size_t)wv * TPW * 32 * 64;
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) bias[t] = bl[16 * (wv * TPW + t) + col];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) bq[0][t] = Ww[(size_t)t * 32 * 64 + lane];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) aq[0][g] = X[(16 * g + col) * LDX + q];
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 32) {
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) bq[nxt][t] = Ww[((size_t)t * 32 + ks + 1) * 64 + lane];
-                // A fragments: lane holds X[row = lane&15 (+16 g)][k = 4 ks + (lane>>4)]
-#pragma unroll
-                for (int g = 0; g < NG; ++g) aq[nxt][g] = X[(16 * g + col) * LDX + 4 * (ks + 1) + q];
+        // ---- layer 8 (one output): dot products on the vector ALU, rows split over lanes
+        for (int r = tid; r < ROWS; r += NT) {
+            double acc = 0.0;
+            for (int j = 0; j < H; ++j) acc += W8[j] * X[r * LDX + j];
+            const int quant = TAN ? (r % 16) / 4 : 0, p = TAN ? 4 * (r / 16) + (r % 4) : r, gp = base + p;
+            if (gp < n) {
+                if (quant == 0) Q.sdf[gp] = acc + b8[0];
+                else Q.grad[3 * gp + quant - 1] = acc;
             }
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g][t] = mfma(aq[cur][g], bq[cur][t], acc[g][t]);
         }
-        __syncthreads();
-        // epilogue: this lane owns (value, dx, dy, dz) of point q (of group g) for neuron 16 t + col
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int j = 16 * (wv * TPW + t) + col;
-                double h, dh;
-                softplus100(comp(acc[g][t], 0) + bias[t], h, dh);
-                X[(16 * g + q) * LDX + j] = h;
-                for (int d = 1; d < 4; ++d) X[(16 * g + 4 * d + q) * LDX + j] = dh * comp(acc[g][t], d);
-            }
-        __syncthreads();
-    }
-    // ---- layer 8 (one output): dot products on the vector ALU, rows split over lanes
-    for (int r = tid; r < ROWS; r += NT) {
-        double acc = 0.0;
-        for (int j = 0; j < H; ++j) acc += W8[j] * X[r * LDX + j];
-        const int quant = (r % 16) / 4, p = 4 * (r / 16) + (r % 4), gp = base + p;
-        if (gp < n) {
-            if (quant == 0) sdf[gp] = acc + b8[0];
-            else grad[3 * gp + quant - 1] = acc;
-        }
+        __syncthreads();   // the next tile's layer 0 overwrites X
     }
 }
 
-template <int NW, int NG>
-void launch(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp, const double *bh,
-            const double *W8, const double *b8, int n, double *sdf, double *grad, int wrt_latent, hipStream_t stream)
+template <int NW, int NG, int MODE>
+void launch(const Query &Q, const DssIgrNet &N, int n_cap, hipStream_t stream)
 {
-    constexpr int PTS = 4 * NG;
-    const size_t lds = (size_t)4 * PTS * LDX * sizeof(double);
+    constexpr int PTS = (MODE == MODE_VALUE ? 16 : 4) * NG;
+    const size_t lds = (size_t)16 * NG * LDX * sizeof(double);
 #if !defined(DSS_EMU)
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)igr_query_kernel<NW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igr_query_kernel<NW, NG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    hipLaunchKernelGGL((igr_query_kernel<NW, NG>), dim3((n + PTS - 1) / PTS), dim3(64 * NW), lds, stream, pts, latent, W0, b0,
-                       Wp, bh, W8, b8, n, sdf, grad, wrt_latent);
+    long tiles = ((long)n_cap + PTS - 1) / PTS;
+    // a list whose length is only known on the device gets a grid that fills the chip (2 workgroups per CU and a few
+    // rounds); surplus workgroups leave at once
+    const long cap = Q.n_dev ? 256L * 2 * 4 : (1L << 30);
+    if (tiles > cap) tiles = cap;
+    if (tiles < 1) tiles = 1;
+    hipLaunchKernelGGL((igr_query_kernel<NW, NG, MODE>), dim3((unsigned)tiles), dim3(64 * NW), lds, stream, Q, N.W0, N.b0, N.Wp,
+                       N.bh, N.W8, N.b8);
 }
+
+template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_cap, hipStream_t stream)
+{
+    // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 4 row groups, halving the L2
+    // weight traffic; small ones: 2 waves x 2 groups so the grid still covers the chip.  Both give bit-identical results.
+    if (n_cap >= 16 * 1024) launch<4, 4, MODE>(Q, N, n_cap, stream);
+    else launch<2, 2, MODE>(Q, N, n_cap, stream);
+}
+
+inline bool net_ok(const DssIgrNet *N) { return N && N->W0 && N->b0 && N->Wp && N->bh && N->W8 && N->b8; }
 
 }  // namespace
 
-extern "C" {
+namespace dss {
+// used by the neural narrow phase (narrowphase_igr.hip) and the reverse sweep: one evaluation round over a device-side list
+int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
+                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream)
+{
+    Query Q{pts, lat_idx, latents, lat_stride, n_dev, n_cap, sdf, grad};
+    if (mode == MODE_VALUE) launch_mode<MODE_VALUE>(Q, N, n_cap, stream);
+    else if (mode == MODE_LATENT) launch_mode<MODE_LATENT>(Q, N, n_cap, stream);
+    else launch_mode<MODE_XYZ>(Q, N, n_cap, stream);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+}  // namespace dss
 
+extern "C" {
 
 size_t dss_igr_packed_doubles(void) { return (size_t)7 * 8 * 32 * 64; }
 
@@ -163,11 +234,8 @@ int dss_igr_query(const double *pts, const double *latent, const double *W0, con
                   const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream)
 {
     if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
-    // big batches (grid builds): 4 waves share 16 points, halving the L2 weight traffic; small ones (contact queries):
-    // 2 waves x 8 points so the grid still covers the chip.  Both give bit-identical results.
-    if (n >= 16 * 1024) launch<4, 4>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 0, (hipStream_t)stream);
-    else launch<2, 2>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 0, (hipStream_t)stream);
-    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+    const DssIgrNet N{W0, b0, Wp, bh, W8, b8};
+    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_XYZ, sdf, grad, (hipStream_t)stream);
 }
 
 // The same network evaluation with the tangents seeded on the latent code instead of the point: grad [n][3] =
@@ -177,9 +245,17 @@ int dss_igr_query_latent_grad(const double *pts, const double *latent, const dou
                               const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream)
 {
     if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
-    if (n >= 16 * 1024) launch<4, 4>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 1, (hipStream_t)stream);
-    else launch<2, 2>(pts, latent, W0, b0, Wp, bh, W8, b8, n, sdf, grad, 1, (hipStream_t)stream);
-    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+    const DssIgrNet N{W0, b0, Wp, bh, W8, b8};
+    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_LATENT, sdf, grad, (hipStream_t)stream);
+}
+
+int dss_igr_query_list(const DssIgrNet *net, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
+                       const int *n_dev, int n_cap, int mode, double *sdf, double *grad, void *stream)
+{
+    if (!net_ok(net) || !pts || !latents || !sdf || n_cap <= 0 || lat_stride < 2) return DSS_E_BADARG;
+    if (mode != MODE_VALUE && mode != MODE_XYZ && mode != MODE_LATENT) return DSS_E_BADARG;
+    if (mode != MODE_VALUE && !grad) return DSS_E_BADARG;
+    return dss::launch_igr_list(*net, pts, lat_idx, latents, lat_stride, n_dev, n_cap, mode, sdf, grad, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -26,102 +26,11 @@
 #ifndef DSS_ALL_SHAPES
 #define DSS_ALL_SHAPES 0
 #endif
-// 3-D hull of a contact cluster with Qhull's vertex semantics (coincident points are one vertex, points in a triangle of
-// others are none).  Needed by every variant: neighbouring faces of an icosphere converge to shared vertices too.
-#define DSS_HULL_EXACT 1
-#include <math.h>
-#include <stdlib.h>
 
-#include "../../include/diffsdfsim_hip.h"
-#include "contact_geom.h"
-#include "wave_utils.h"
+
+#include "np_common.h"
 
 namespace {
-using namespace dss;
-
-constexpr int NT = 256;
-constexpr int MAX_CPT = 8;       // moving candidates per thread of a group: HCAP <= BT * MAX_CPT
-constexpr int HULL3_MAX = 48;    // brute-force 3-D hull size limit
-// Every item starts on a single wavefront, whatever the size of the mesh it searches: the culling boxes of the 176 k-face
-// floor are 688 tests (11 rounds of 64 lanes), after which the item is as small as any other, and a workgroup item keeps
-// four wavefronts busy for what is mostly a serial chain.  Items that outgrow the wavefront's scratch are deferred.
-constexpr int WAVE_ITEM_MAX_FACES = 1 << 30;
-
-__device__ inline int npairs_of(int nb) { return nb * (nb - 1); }
-__device__ inline void pair_of(int dp, int nb, int &a, int &b)
-{
-    a = dp / (nb - 1);
-    const int r = dp % (nb - 1);
-    b = r < a ? r : r + 1;
-}
-
-struct BodyD {
-    BodyG<double> g;
-    int mesh, voff, nv, foff, nf;
-};
-
-__device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
-{
-    const double *ps = W.pose + ((size_t)sc * W.nb + b) * 7;
-    for (int i = 0; i < 4; ++i) o.g.q[i] = ps[i];
-    for (int i = 0; i < 3; ++i) o.g.pos[i] = ps[4 + i];
-    const double *prm = W.shape_prm + ((size_t)sc * W.nb + b) * 3;
-#if DSS_ALL_SHAPES
-    make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm, W.shape_aux[(size_t)sc * W.nb + b]);
-#else
-    make_shape(o.g.shape, W.shape_type[(size_t)sc * W.nb + b], prm);
-#endif
-    // the same for every lane: keep it in scalar registers (frees ~60 VGPRs in the narrow phase)
-    for (int i = 0; i < 4; ++i) o.g.q[i] = dss_uniform(o.g.q[i]);
-    for (int i = 0; i < 3; ++i) {
-        o.g.pos[i] = dss_uniform(o.g.pos[i]);
-        o.g.shape.prm[i] = dss_uniform(o.g.shape.prm[i]);
-        o.g.shape.hd[i] = dss_uniform(o.g.shape.hd[i]);
-    }
-    o.g.shape.scale = dss_uniform(o.g.shape.scale);
-#if DSS_ALL_SHAPES
-    o.g.shape.hr = dss_uniform(o.g.shape.hr);
-#endif
-    o.g.shape.type = dss_uniform(o.g.shape.type);
-    o.mesh = W.mesh_id[(size_t)sc * W.nb + b];
-    o.voff = W.mesh_voff[o.mesh]; o.nv = W.mesh_nv[o.mesh];
-    o.foff = W.mesh_foff[o.mesh]; o.nf = W.mesh_nf[o.mesh];
-}
-
-// vertex of body `a` (body frame) -> frame of body b, in the reference's order of operations:
-// world = R_a v + x_a (get_surface, bodies.py:716-719), then R_b^-1 (world - x_b) (contacts.py:42)
-__device__ inline void to_frame(const BodyG<double> &a, const BodyG<double> &b, const double *v, double *o)
-{
-    double w[3], r[3];
-    quat_apply(a.q, v, w);
-    for (int i = 0; i < 3; ++i) r[i] = (w[i] + a.pos[i]) - b.pos[i];
-    quat_apply_inv(b.q, r, o);
-}
-
-
-// axis-aligned box, in the body frame of `a`, that contains body b's query cube [-s,s]^3 (+ margin)
-struct Region { double c[3], e[3]; };
-__device__ inline void region_of(const BodyG<double> &a, const BodyG<double> &b, double margin, Region &r)
-{
-    double Ra[9], Rb[9];
-    quat_to_mat(a.q, Ra);
-    quat_to_mat(b.q, Rb);
-    const double d[3] = {b.pos[0] - a.pos[0], b.pos[1] - a.pos[1], b.pos[2] - a.pos[2]};
-    const double s = b.shape.scale;
-    for (int i = 0; i < 3; ++i) {
-        r.c[i] = Ra[i] * d[0] + Ra[3 + i] * d[1] + Ra[6 + i] * d[2];          // R_a^T (x_b - x_a)
-        double e = 0.0;
-        for (int j = 0; j < 3; ++j) e += fabs(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);   // |R_a^T R_b|
-        r.e[i] = s * e * (1.0 + 1e-9) + margin;
-    }
-}
-__device__ inline bool box_hits(const Region &r, const double *bx)
-{
-    for (int i = 0; i < 3; ++i)
-        if (bx[i] > r.c[i] + r.e[i] || bx[3 + i] < r.c[i] - r.e[i]) return false;
-    return true;
-}
-
 // ---- _overlap ---------------------------------------------------------------------------------
 // "Does any vertex of one body lie in the other's query cube", both ways, for every undirected pair.  One workgroup
 // per scene, its four wavefronts take the pairs round robin (no barrier inside a pair: the work per pair is a short
@@ -137,6 +46,11 @@ __global__ void __launch_bounds__(OV_NT) overlap_kernel(DssWorld W)
     const int sc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!W.active[sc]) return;
     if (tid < nb) s_big[tid] = W.mesh_nf[W.mesh_id[(size_t)sc * nb + tid]] > WAVE_ITEM_MAX_FACES;
+#if DSS_ALL_SHAPES
+    // a pair with a neural SDF body goes to the round-based narrow phase (narrowphase_igr.hip), both directions
+    __shared__ unsigned char s_igr[64];
+    if (tid < nb) s_igr[tid] = W.shape_type[(size_t)sc * nb + tid] == DSS_SHAPE_IGR;
+#endif
     for (int up = wv; up < nup; up += OV_NT / 64) {
         int i = 0, rem = up;
         while (rem >= nb - 1 - i) { rem -= nb - 1 - i; ++i; }
@@ -190,6 +104,26 @@ __global__ void __launch_bounds__(OV_NT) overlap_kernel(DssWorld W)
     // list 0: items a whole workgroup works on (big mesh searched), list 1: one wavefront each
     if (tid == 0) {
         int cnt[2] = {0, 0};
+#if DSS_ALL_SHAPES
+        int nig = 0;
+        for (int up = 0, i = 0, j = 1; up < nup; ++up) {
+            if (s_ok[up] && (s_igr[i] || s_igr[j])) nig += 2;
+            if (++j == nb) { ++i; j = i + 1; }
+        }
+        if (nig) {
+            int at = atomicAdd(W.n_pairs + 6, nig);
+            for (int up = 0, i = 0, j = 1; up < nup; ++up) {
+                if (s_ok[up] && (s_igr[i] || s_igr[j])) {
+                    s_ok[up] = 0;     // not an item of the analytic lists
+                    if (W.igr_list && at + 2 <= W.igr_items_cap) {
+                        W.igr_list[at++] = sc * np + i * (nb - 1) + (j - 1);
+                        W.igr_list[at++] = sc * np + j * (nb - 1) + i;
+                    } else atomicOr(W.overflow + sc, 32);
+                }
+                if (++j == nb) { ++i; j = i + 1; }
+            }
+        }
+#endif
         for (int up = 0, i = 0, j = 1; up < nup; ++up) {
             if (s_ok[up]) { ++cnt[s_big[i] ? 0 : 1]; ++cnt[s_big[j] ? 0 : 1]; }
             if (++j == nb) { ++i; j = i + 1; }
@@ -208,435 +142,6 @@ __global__ void __launch_bounds__(OV_NT) overlap_kernel(DssWorld W)
             if (++j == nb) { ++i; j = i + 1; }
         }
     }
-}
-
-// ---- workgroup scratch ------------------------------------------------------------------------
-// A work item (scene, directed pair a->b) is processed by a GROUP of threads: a whole 256-thread workgroup when
-// a's mesh is big (the 176 k-face floor), a single wavefront otherwise.  Most of the item is a serial chain
-// (Frank-Wolfe iterations of a handful of movers, greedy clustering, gift wrapping), so four independent
-// wavefronts per workgroup keep four times as many chains in flight; the wave flavour needs no s_barrier at all.
-//   BT    threads of the group             HCAP  capacity of the mover list / of one normal cluster
-//   CHCAP runs of 256 faces the barrier-free scan can hold (176 k-face floor = 688 runs)
-template <int BT_, int HCAP_, int CHCAP_> struct Group {
-    static constexpr int BT = BT_, HCAP = HCAP_, CHCAP = CHCAP_, NW = BT_ / 64;
-    __device__ static inline int tid() { return BT_ == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
-    __device__ static inline void sync() { if (BT_ == 64) dss_wave_sync(); else __syncthreads(); }
-    __device__ static inline int any(int x) { if (BT_ == 64) return __ballot(x) != 0ull; else return __syncthreads_or(x); }
-};
-using BlockGroup = Group<256, 1024, 704>;
-using WaveGroup = Group<64, 384, 32>;
-
-template <class G> struct ScratchT {
-    int wave_tot[G::NW];
-    int woff[G::BT == 64 ? 1 : G::CHCAP * 4];   // (workgroup scan only)
-    int vote[2][G::NW];
-    int red_i[G::BT];
-    double red_d[G::BT];
-    double hp[3 * G::HCAP];   // cluster points for the hull
-    int hidx[G::HCAP];
-    unsigned char hflag[G::HCAP];
-    unsigned char cst[G::HCAP];   // filter state of a contact: 0 unassigned, 1 clustered, 2 kept, 255 no normal
-};
-
-// ordered compaction: returns this thread's output slot (or -1) and updates the running count
-template <class G> __device__ inline int compact_slot(int flag, int &count, ScratchT<G> &S)
-{
-    const int tid = G::tid(), lane = tid & 63, wv = tid >> 6;
-    const unsigned long long m = __ballot(flag);
-    const int pre = __popcll(m & ((1ull << lane) - 1ull)), tot = __popcll(m);
-    if (G::BT == 64) { const int off1 = count; count += tot; return flag ? off1 + pre : -1; }
-    if (lane == 0) S.wave_tot[wv] = tot;
-    G::sync();
-    int off = count, all = 0;
-    for (int w = 0; w < G::BT / 64; ++w) { if (w < wv) off += S.wave_tot[w]; all += S.wave_tot[w]; }
-    G::sync();
-    count += all;
-    return flag ? off + pre : -1;
-}
-
-// block arg-min over (key, index) with lowest index on ties; returns the index (or -1 if none valid)
-// value of lane 0, for every lane (the xor butterfly leaves the same set summed in every lane, but only lane 0's
-// order of additions is that of the LDS tree the workgroup flavour uses)
-__device__ inline double wave_first(double x)
-{
-#if defined(DSS_EMU)
-    return __shfl(x, 0, 64);
-#else
-    return dss_uniform(x);
-#endif
-}
-template <class G> __device__ inline int block_argmin(double key, int idx, ScratchT<G> &S)
-{
-    if (G::BT == 64) {   // one wavefront: shuffles, no LDS round trips; (key, index) minimum is order independent
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ok = __shfl_xor(key, o, 64);
-            const int oi = __shfl_xor(idx, o, 64);
-            if (oi >= 0 && (idx < 0 || ok < key || (ok == key && oi < idx))) { key = ok; idx = oi; }
-        }
-        return idx;
-    }
-    const int tid = G::tid();
-    S.red_d[tid] = key; S.red_i[tid] = idx;
-    G::sync();
-    for (int s = G::BT / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            const double ok = S.red_d[tid + s]; const int oi = S.red_i[tid + s];
-            const int mi = S.red_i[tid];
-            if (oi >= 0 && (mi < 0 || ok < S.red_d[tid] || (ok == S.red_d[tid] && oi < mi))) { S.red_d[tid] = ok; S.red_i[tid] = oi; }
-        }
-        G::sync();
-    }
-    const int r = S.red_i[0];
-    G::sync();
-    return r;
-}
-template <class G> __device__ inline double block_max(double v, ScratchT<G> &S)
-{
-    if (G::BT == 64) return wave_max_dpp(v);
-    const int tid = G::tid();
-    S.red_d[tid] = v;
-    G::sync();
-    for (int s = G::BT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] = fmax(S.red_d[tid], S.red_d[tid + s]); G::sync(); }
-    const double r = S.red_d[0];
-    G::sync();
-    return r;
-}
-template <class G> __device__ inline double block_sum(double v, ScratchT<G> &S)
-{
-    if (G::BT == 64) return wave_first(wave_sum(v));   // same association as the tree below, bit for bit
-    const int tid = G::tid();
-    S.red_d[tid] = v;
-    G::sync();
-    for (int s = G::BT / 2; s > 0; s >>= 1) { if (tid < s) S.red_d[tid] += S.red_d[tid + s]; G::sync(); }
-    const double r = S.red_d[0];
-    G::sync();
-    return r;
-}
-
-// ---- hull of one normal cluster (points in S.hp, m of them); marks S.hflag ---------------------
-// Mirrors the fall-back ladder of contacts.py:126-152: 3-D hull; if Qhull would reject the input as
-// flat drop the coordinate of least variance and retry in 2-D; then 1-D min/max.
-// where a cluster's points and keep-flags live while its hull is taken: in LDS (clusters of up to HCAP points) or, for the
-// clusters a level-set mesh resting flat on a neighbour produces (every face of the resting side), in the group's global
-// candidate scratch (rows 3-6 of cand_buf, dead after the contact geometry stage)
-template <class G> struct HullLds {
-    ScratchT<G> *S;
-    __device__ inline double hp(int k, int d) const { return S->hp[3 * k + d]; }
-    __device__ inline int getf(int k) const { return S->hflag[k]; }
-    __device__ inline void setf(int k, int v) const { S->hflag[k] = (unsigned char)v; }
-};
-struct HullGlobal {
-    double *cb; int mc;
-    __device__ inline double hp(int k, int d) const { return cb[(size_t)(3 + d) * mc + k]; }
-    __device__ inline int getf(int k) const { return (int)cb[(size_t)6 * mc + k]; }
-    __device__ inline void setf(int k, int v) const { cb[(size_t)6 * mc + k] = (double)v; }
-};
-
-template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
-{
-    const int tid = G::tid();
-    for (int k = tid; k < m; k += G::BT) P.setf(k, 0);
-    G::sync();
-    if (m == 1) { if (tid == 0) P.setf(0, 1); G::sync(); return; }
-    // per-coordinate mean / unbiased variance (torch.var)
-    double mean[3], var[3], amax = 0.0;
-    for (int d = 0; d < 3; ++d) {
-        double acc = 0.0, mx = 0.0;
-        for (int k = tid; k < m; k += G::BT) { acc += P.hp(k, d); mx = fmax(mx, fabs(P.hp(k, d))); }
-        mean[d] = block_sum(acc, S) / m;
-        amax = fmax(amax, block_max(mx, S));
-        acc = 0.0;
-        for (int k = tid; k < m; k += G::BT) { const double t = P.hp(k, d) - mean[d]; acc += t * t; }
-        var[d] = block_sum(acc, S) / (m - 1);
-    }
-    const double tolf = 1e-12 * (1.0 + amax);
-    // distance tolerance of the 2-D hull: Qhull merges a vertex that clears its neighbours' edge by less than ~6e-15 of the
-    // extent (its `_one-merge`); a box that has turned by 4e-15 rad puts its mid-edge contact points 2e-15 off the edge
-    // (dropped there), the smallest excursion seen kept is 4e-11
-    const double dtol = 2e-14 * (1.0 + amax), dtol2 = dtol * dtol;
-    // farthest point B from A = point 0, then C farthest from line AB
-    const double A[3] = {P.hp(0, 0), P.hp(0, 1), P.hp(0, 2)};
-    double key = -1.0; int ki = -1;
-    for (int k = tid; k < m; k += G::BT) {
-        const double d0 = P.hp(k, 0) - A[0], d1 = P.hp(k, 1) - A[1], d2 = P.hp(k, 2) - A[2];
-        const double dd = d0 * d0 + d1 * d1 + d2 * d2;
-        if (dd > key) { key = dd; ki = k; }
-    }
-    const int iB = block_argmin(-key, ki, S);
-    double ab[3] = {P.hp(iB, 0) - A[0], P.hp(iB, 1) - A[1], P.hp(iB, 2) - A[2]};
-    const double lab = sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
-    bool flat3 = (m < 4) || !(lab > tolf), line = !(lab > tolf);
-    double nrm[3] = {0, 0, 0};
-    if (!line) {
-        key = -1.0; ki = -1;
-        for (int k = tid; k < m; k += G::BT) {
-            const double d[3] = {P.hp(k, 0) - A[0], P.hp(k, 1) - A[1], P.hp(k, 2) - A[2]};
-            double c[3];
-            cross(ab, d, c);
-            const double dd = (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-            if (dd > key) { key = dd; ki = k; }
-        }
-        const int iC = block_argmin(-key, ki, S);
-        const double ac[3] = {P.hp(iC, 0) - A[0], P.hp(iC, 1) - A[1], P.hp(iC, 2) - A[2]};
-        cross(ab, ac, nrm);
-        const double ln = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        if (!(ln / lab > tolf)) { line = true; flat3 = true; }
-        else {
-            for (int d = 0; d < 3; ++d) nrm[d] /= ln;
-            double mx = -INFINITY, mn = INFINITY; int imx = -1, imn = -1;
-            for (int k = tid; k < m; k += G::BT) {
-                const double sd = nrm[0] * (P.hp(k, 0) - A[0]) + nrm[1] * (P.hp(k, 1) - A[1]) + nrm[2] * (P.hp(k, 2) - A[2]);
-                if (sd > mx) { mx = sd; imx = k; }
-                if (sd < mn) { mn = sd; imn = k; }
-            }
-            const int gmx = block_argmin(-mx, imx, S), gmn = block_argmin(mn, imn, S);
-            const double dmx = nrm[0] * (P.hp(gmx, 0) - A[0]) + nrm[1] * (P.hp(gmx, 1) - A[1]) + nrm[2] * (P.hp(gmx, 2) - A[2]);
-            const double dmn = nrm[0] * (P.hp(gmn, 0) - A[0]) + nrm[1] * (P.hp(gmn, 1) - A[1]) + nrm[2] * (P.hp(gmn, 2) - A[2]);
-            const double thick = fmax(fabs(dmx), fabs(dmn));
-            if (!(thick > tolf)) flat3 = true;
-            else if (thick <= 1e-6 * (1.0 + amax) && m >= 4) {
-                // a sliver: its 3-D hull is the 2-D hull of the projection plus the points that stick out of
-                // the plane (Qhull keeps those as vertices; anything flatter than round-off it rejects outright)
-                flat3 = true;
-                if (tid == 0) { if (fabs(dmx) > tolf) P.setf(gmx, 2); if (fabs(dmn) > tolf) P.setf(gmn, 2); }   // 2 = kept, not a visited hull vertex
-                G::sync();
-            }
-        }
-    }
-#if DSS_HULL_EXACT
-    if (!flat3 && m > 2048) {   // beyond what the pairwise duplicate search below is meant for: keep every point
-        for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
-        G::sync();
-        return;
-    }
-    if (!flat3) {
-        // Coincident points (candidates of neighbouring faces that converged to a shared mesh vertex -- the rule on a
-        // level-set mesh) are one hull vertex to Qhull: the first of each group stands for it.  3 = duplicate.
-        for (int k = tid; k < m; k += G::BT) {
-            int dup = 0;
-            for (int j = 0; j < k && !dup; ++j) {
-                const double d0 = P.hp(k, 0) - P.hp(j, 0), d1 = P.hp(k, 1) - P.hp(j, 1), d2 = P.hp(k, 2) - P.hp(j, 2);
-                dup = !(d0 * d0 + d1 * d1 + d2 * d2 > tolf * tolf);
-            }
-            if (dup) P.setf(k, 3);
-        }
-        G::sync();
-        static_assert(HULL3_MAX <= 64, "the list of distinct points lives in red_i");
-        if (tid == 0) {
-            int mu = 0;
-            for (int k = 0; k < m; ++k) if (P.getf(k) != 3) { if (mu < HULL3_MAX) S.red_i[mu] = k; ++mu; }
-            S.wave_tot[0] = mu;
-        }
-        G::sync();
-        const int mu = S.wave_tot[0];
-        G::sync();
-        if (mu > HULL3_MAX) {
-            // Beyond the brute-force limit: a superset of the hull's vertices -- every distinct point, except (full
-            // variant, up to 512 points) those that lie on the segment between two other points.  That is what a curved
-            // level-set surface in line contact needs (a cylinder lying on the floor: rows of collinear contact points
-            // along its length, of which only the two ends of a row are vertices).
-#if DSS_ALL_SHAPES
-            // the distinct points, listed once (workgroup: in the scan's LDS words, free by now; a wavefront's cluster is
-            // small enough to walk with its duplicates)
-            constexpr int UCAP = G::BT == 64 ? 1 : 512;
-            const bool listed = G::BT != 64 && mu <= UCAP;
-            if (listed && tid == 0) { int u = 0; for (int k = 0; k < m; ++k) if (P.getf(k) != 3) S.woff[u++] = k; }
-            G::sync();
-            const bool thin = listed || (G::BT == 64 && mu <= 512);
-            const int nu = listed ? mu : m;
-#else
-            const bool thin = false, listed = false;
-            const int nu = m;
-#endif
-            for (int q = tid; q < m; q += G::BT) {
-                int keep = P.getf(q) != 3;
-                if (keep && thin) {
-                    const double qx = P.hp(q, 0), qy = P.hp(q, 1), qz = P.hp(q, 2);
-                    for (int ia = 0; ia < nu && keep; ++ia) {
-                        const int a = listed ? S.woff[ia] : ia;
-                        if (a == q || P.getf(a) == 3) continue;
-                        const double ax = P.hp(a, 0) - qx, ay = P.hp(a, 1) - qy, az = P.hp(a, 2) - qz;
-                        for (int ib = ia + 1; ib < nu; ++ib) {
-                            const int b = listed ? S.woff[ib] : ib;
-                            if (b == q || P.getf(b) == 3) continue;
-                            const double bx = P.hp(b, 0) - qx, by = P.hp(b, 1) - qy, bz = P.hp(b, 2) - qz;
-                            if (!(ax * bx + ay * by + az * bz < 0.0)) continue;          // q is not between a and b
-                            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-                            const double ex = bx - ax, ey = by - ay, ez = bz - az;
-                            // distance of q from the line a-b, squared: |a x b|^2 / |b - a|^2
-                            if (cx * cx + cy * cy + cz * cz <= tolf * tolf * (ex * ex + ey * ey + ez * ez)) { keep = 0; break; }
-                        }
-                    }
-                }
-                if (P.getf(q) != 3) P.setf(q, keep ? 1 : 4);      // other threads only ask whether a flag is 3
-            }
-            G::sync();
-            for (int k = tid; k < m; k += G::BT) { const int f = P.getf(k); P.setf(k, f == 1 ? 1 : 0); }
-            G::sync();
-            return;
-        }
-        // supporting-plane test over all triples of distinct points.  A point that lies in the triangle of three others
-        // (inside it or on one of its edges) is no hull vertex, whatever planes it helps to support: Qhull reports the
-        // extreme points only, a level-set mesh puts rows of equidistant vertices on every straight edge.
-        for (int q = tid; q < mu; q += G::BT) S.red_d[q] = 0.0;      // 1 = lies in a triangle of other points
-        G::sync();
-        const int ntri = mu * mu * mu;
-        for (int e = tid; e < ntri; e += G::BT) {
-            const int iu = e / (mu * mu), ju = (e / mu) % mu, ku = e % mu;
-            if (!(iu < ju && ju < ku)) continue;
-            const int i = S.red_i[iu], j = S.red_i[ju], k = S.red_i[ku];
-#else
-    if (!flat3) {
-        if (m > HULL3_MAX) {  // beyond the brute-force limit: keep every point (superset of the hull)
-            for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
-            G::sync();
-            return;
-        }
-        // supporting-plane test over all triples
-        const int ntri = m * m * m;
-        for (int e = tid; e < ntri; e += G::BT) {
-            const int i = e / (m * m), j = (e / m) % m, k = e % m;
-            if (!(i < j && j < k)) continue;
-#endif
-            const double u[3] = {P.hp(j, 0) - P.hp(i, 0), P.hp(j, 1) - P.hp(i, 1), P.hp(j, 2) - P.hp(i, 2)};
-            const double v[3] = {P.hp(k, 0) - P.hp(i, 0), P.hp(k, 1) - P.hp(i, 1), P.hp(k, 2) - P.hp(i, 2)};
-            double n[3];
-            cross(u, v, n);
-            const double ln = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-            if (!(ln > 1e-14 * (1.0 + amax) * (1.0 + amax))) continue;
-            int pos = 0, neg = 0;
-            for (int q = 0; q < m; ++q) {
-                const double sd = (n[0] * (P.hp(q, 0) - P.hp(i, 0)) + n[1] * (P.hp(q, 1) - P.hp(i, 1)) + n[2] * (P.hp(q, 2) - P.hp(i, 2))) / ln;
-                pos |= sd > tolf; neg |= sd < -tolf;
-            }
-#if DSS_HULL_EXACT
-            for (int qu = 0; qu < mu; ++qu) {
-                const int q = S.red_i[qu];
-                if (q == i || q == j || q == k) continue;
-                const double w[3] = {P.hp(q, 0) - P.hp(i, 0), P.hp(q, 1) - P.hp(i, 1), P.hp(q, 2) - P.hp(i, 2)};
-                if (fabs(n[0] * w[0] + n[1] * w[1] + n[2] * w[2]) / ln > tolf) continue;      // not in the triangle's plane
-                // barycentric coordinates of q in (i, j, k): areas of the sub-triangles over the area of the triangle
-                double c1[3], c2[3];
-                cross(w, v, c1);
-                cross(u, w, c2);
-                const double bj = (c1[0] * n[0] + c1[1] * n[1] + c1[2] * n[2]) / (ln * ln);
-                const double bk = (c2[0] * n[0] + c2[1] * n[1] + c2[2] * n[2]) / (ln * ln);
-                if (bj >= -1e-9 && bk >= -1e-9 && 1.0 - bj - bk >= -1e-9) S.red_d[qu] = 1.0;
-            }
-#endif
-            if (!(pos && neg)) { P.setf(i, 1); P.setf(j, 1); P.setf(k, 1); }
-        }
-        G::sync();
-#if DSS_HULL_EXACT
-        for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
-        for (int qu = tid; qu < mu; qu += G::BT) if (S.red_d[qu] != 0.0) P.setf(S.red_i[qu], 0);
-        G::sync();
-#endif
-        return;
-    }
-    // ---- 2-D: drop the coordinate of least variance (first index on ties, torch.argmin) ---------
-    int drop = 0;
-    for (int d = 1; d < 3; ++d) if (var[d] < var[drop]) drop = d;
-    if (var[0] != var[0]) drop = 0;
-    const int c0 = drop == 0 ? 1 : 0, c1 = drop == 2 ? 1 : 2;
-    bool collinear = (m < 3);
-    int iS = -1;
-    if (!collinear) {
-        // start: lexicographic minimum.  "Equal" first coordinates are equal to round-off: contact points along a box edge
-        // are collinear in the body frame and pick up 1e-17 of noise in the rotation to the world frame; taking the
-        // bare minimum would start (and keep) a point from the middle of that edge
-        double k0 = INFINITY; int k0i = -1;
-        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) < k0) { k0 = P.hp(k, c0); k0i = k; }
-        const int i0 = block_argmin(k0, k0i, S);
-        const double x0 = P.hp(i0, c0);
-        k0 = INFINITY; k0i = -1;
-        const double xtol = dtol;
-        for (int k = tid; k < m; k += G::BT) if (P.hp(k, c0) <= x0 + xtol && P.hp(k, c1) < k0) { k0 = P.hp(k, c1); k0i = k; }
-        iS = block_argmin(k0, k0i, S);
-        // collinearity: farthest point from the start, then max distance to that line
-        key = -1.0; ki = -1;
-        for (int k = tid; k < m; k += G::BT) {
-            const double d0 = P.hp(k, c0) - P.hp(iS, c0), d1 = P.hp(k, c1) - P.hp(iS, c1);
-            if (d0 * d0 + d1 * d1 > key) { key = d0 * d0 + d1 * d1; ki = k; }
-        }
-        const int iF = block_argmin(-key, ki, S);
-        const double e0 = P.hp(iF, c0) - P.hp(iS, c0), e1 = P.hp(iF, c1) - P.hp(iS, c1);
-        const double le = sqrt(e0 * e0 + e1 * e1);
-        if (!(le > tolf)) collinear = true;
-        else {
-            double mx = 0.0;
-            for (int k = tid; k < m; k += G::BT)
-                mx = fmax(mx, fabs(e0 * (P.hp(k, c1) - P.hp(iS, c1)) - e1 * (P.hp(k, c0) - P.hp(iS, c0))) / le);
-            if (!(block_max(mx, S) > tolf)) collinear = true;
-        }
-    }
-    if (!collinear) {
-        // gift wrapping, counter-clockwise; collinear candidates: the farthest wins (interior ones dropped)
-        int cur = iS;
-        for (int step = 0; step < m; ++step) {
-            if (tid == 0) P.setf(cur, 1);
-            const double cx = P.hp(cur, c0), cy = P.hp(cur, c1);
-            int best = -1; double bx = 0, by = 0;
-            for (int k = tid; k < m; k += G::BT) {
-                const double qx = P.hp(k, c0) - cx, qy = P.hp(k, c1) - cy;
-                const double lq = qx * qx + qy * qy;
-                if (!(lq > tolf * tolf)) continue;  // the current point or a duplicate of it
-                if (best < 0) { best = k; bx = qx; by = qy; continue; }
-                const double cr = bx * qy - by * qx, lb = bx * bx + by * by;
-                // clockwise of the best so far by more than round-off, or collinear with it and farther.  Measured like
-                // Qhull measures it: the nearer of the two points clears the line through the farther one by more than
-                // a few ulps of the cluster's extent (Qhull merges facets flatter than that and keeps every vertex that
-                // sticks out more: contact points along an edge are collinear to 1e-9 .. 1e-12 only, and whether such a
-                // point survives changes the contact set)
-                const double c2 = cr * cr, t2 = dtol2 * fmax(lb, lq);
-                if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && lq > lb)) { best = k; bx = qx; by = qy; }
-            }
-            S.red_i[tid] = best;
-            G::sync();
-            for (int s = G::BT / 2; s > 0; s >>= 1) {
-                if (tid < s) {
-                    const int a = S.red_i[tid], b = S.red_i[tid + s];
-                    if (b >= 0) {
-                        if (a < 0) S.red_i[tid] = b;
-                        else {
-                            const double ax = P.hp(a, c0) - cx, ay = P.hp(a, c1) - cy;
-                            const double qx = P.hp(b, c0) - cx, qy = P.hp(b, c1) - cy;
-                            const double cr = ax * qy - ay * qx, la = ax * ax + ay * ay, lq = qx * qx + qy * qy;
-                            const double c2 = cr * cr, t2 = dtol2 * fmax(la, lq);
-                            if ((cr < 0.0 && c2 > t2) || (c2 <= t2 && (lq > la || (lq == la && b < a)))) S.red_i[tid] = b;
-                        }
-                    }
-                }
-                G::sync();
-            }
-            const int nxt = S.red_i[0];
-            const int seen = nxt >= 0 ? (P.getf(nxt) == 1) : 0;
-            G::sync();   // every thread has read red_i / hflag before thread 0 flags the next vertex
-            if (nxt < 0 || nxt == iS || seen) break;
-            {   // coincident with the start (shared mesh vertices produce exact duplicates): the loop is closed
-                const double dx = P.hp(nxt, c0) - P.hp(iS, c0), dy = P.hp(nxt, c1) - P.hp(iS, c1);
-                if (!(dx * dx + dy * dy > tolf * tolf)) break;
-            }
-            cur = nxt;
-        }
-        G::sync();
-        return;
-    }
-    // ---- 1-D: drop the next least-variance coordinate, keep min (and max if the spread > eps) ---
-    const int keep = (var[c1] < var[c0]) ? c0 : c1;  // argmin over the remaining two drops the smaller
-    double kmin = INFINITY, kmax = -INFINITY; int imin = -1, imax = -1;
-    for (int k = tid; k < m; k += G::BT) {
-        const double v = P.hp(k, keep);
-        if (v < kmin) { kmin = v; imin = k; }
-        if (v > kmax) { kmax = v; imax = k; }
-    }
-    const int gmin = block_argmin(kmin, imin, S), gmax = block_argmin(-kmax, imax, S);
-    if (tid == 0) {
-        P.setf(gmin, 1);
-        if (P.hp(gmax, keep) - P.hp(gmin, keep) > eps) P.setf(gmax, 1);
-    }
-    G::sync();
 }
 
 // ---- the narrow phase -------------------------------------------------------------------------
@@ -1043,140 +548,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         return 0;
     }
 
-    STAMP(4);
-    // ---- 5. filter: greedy normal clusters, hull of each (contacts.py:97-158) -------------------
-    int nkeep = 0;
-    unsigned keptbits = 0u;
-    if (ncon <= 1) {
-        if (tid == 0) cstate[0] = -2;  // kept
-        nkeep = ncon;
-    } else {
-        // The state of every contact lives in LDS bytes while the clusters are formed (a wavefront-sized group needs
-        // ncon <= HCAP anyway; a workgroup falls back to the global array beyond its LDS capacity), and the six
-        // numbers a contact contributes (normal, p1) are fetched in one batch per round: every dependent global
-        // round trip costs a microsecond here.
-        const bool lds_state = ncon <= G::HCAP;
-        if (!lds_state && G::BT == 64) return 1;
-        auto get_state = [&](int k) -> int { return lds_state ? (int)S.cst[k] : cstate[k]; };
-        auto set_state = [&](int k, int v) { if (lds_state) S.cst[k] = (unsigned char)v; else cstate[k] = v; };
-        for (int k = tid; k < ncon; k += G::BT) {
-            const double nn = t_sqrt(CB(18, k) * CB(18, k) + CB(19, k) * CB(19, k) + CB(20, k) * CB(20, k));
-            set_state(k, nn > 1e-12 ? 0 : 255);
-        }
-        G::sync();
-        for (int cl = 1; cl <= ncon; ++cl) {
-            int mine = -1;
-            for (int k = tid; k < ncon; k += G::BT) if (get_state(k) == 0) { mine = k; break; }
-            const int seed = block_argmin(mine >= 0 ? (double)mine : INFINITY, mine, S);
-            if (seed < 0) break;
-            const double sn[3] = {CB(18, seed), CB(19, seed), CB(20, seed)};
-            // gather the cluster (ascending) into the hull scratch
-            int m = 0;
-            for (int base = 0; base < ncon; base += G::BT) {
-                const int k = base + tid;
-                int in = 0;
-                double p1v[3] = {0.0, 0.0, 0.0};
-                if (k < ncon && get_state(k) == 0) {
-                    const double nk[3] = {CB(18, k), CB(19, k), CB(20, k)};
-                    for (int i = 0; i < 3; ++i) p1v[i] = CB(21 + i, k);
-                    const double d = fmin(nk[0] * sn[0] + nk[1] * sn[1] + nk[2] * sn[2], 1.0);
-                    in = acos(d) < 1e-2;
-                }
-#if DSS_ALL_SHAPES
-                const int slot = compact_slot(in, m, S);
-                if (slot >= 0) {
-                    set_state(k, 3);     // member of the cluster being thinned
-                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = p1v[i]; }
-                }
-            }
-            G::sync();
-            if (m <= G::HCAP) {
-                cluster_hull(S, HullLds<G>{&S}, m, W.eps);
-                for (int j = tid; j < m; j += G::BT) set_state(S.hidx[j], S.hflag[j] ? 2 : 1);
-            } else {
-                // more points than the LDS scratch holds (a level-set mesh lying flat on its neighbour: every face of that
-                // side is a contact with the same normal): gather the members again, into the global candidate scratch
-                if (G::BT == 64) return 1;
-                m = 0;
-                for (int base = 0; base < ncon; base += G::BT) {
-                    const int k = base + tid;
-                    const int in = k < ncon && get_state(k) == 3;
-                    const int slot = compact_slot(in, m, S);
-                    if (slot >= 0) { cface[slot] = k; for (int i = 0; i < 3; ++i) CB(3 + i, slot) = CB(21 + i, k); }
-                }
-                G::sync();
-                const HullGlobal P{cb, MC};
-                cluster_hull(S, P, m, W.eps);
-                for (int j = tid; j < m; j += G::BT) set_state(cface[j], P.getf(j) ? 2 : 1);
-            }
-            G::sync();
-        }
-#else
-                const int slot = compact_slot(in, m, S);
-                if (slot >= 0) {
-                    set_state(k, 1);
-                    if (slot < G::HCAP) { S.hidx[slot] = k; for (int i = 0; i < 3; ++i) S.hp[3 * slot + i] = p1v[i]; }
-                }
-            }
-            G::sync();
-            if (m > G::HCAP) { if (G::BT == 64) return 1; over |= 2; m = G::HCAP; }
-            cluster_hull(S, HullLds<G>{&S}, m, W.eps);
-            for (int j = tid; j < m; j += G::BT) if (S.hflag[j]) set_state(S.hidx[j], 2);
-            G::sync();
-        }
-#endif
-        for (int k = tid, r = 0; k < ncon; k += G::BT, ++r) {
-            const int kept = get_state(k) == 2;
-#if DSS_ALL_SHAPES
-            if (r < 32)
-#endif
-            keptbits |= (unsigned)kept << r;     // round r of this thread: the final stage walks the same (round, thread) grid
-            nkeep += kept;
-        }
-        nkeep = (int)(block_sum((double)nkeep, S) + 0.5);
-    }
-
-    STAMP(5);
-    // ---- 6. the kept contacts (geometry from stage 4), in ascending face order --------------------
-    // (the reference emits cluster by cluster in Qhull's vertex order, which is implementation
-    //  defined; contact sets of a pair are compared as sets)
-    int nout = 0;
-    const int MP = W.max_pc;
-    int *pf = W.pc_face + ((size_t)sc * np + dp) * MP;
-    double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
-    if (ncon <= 1) {
-        if (tid == 0) {
-            pf[0] = kface[0];
-            for (int i = 0; i < 3; ++i) { pabc[(size_t)i * MP] = CB(15 + i, 0); pg[(size_t)i * MP] = CB(18 + i, 0); pg[(size_t)(3 + i) * MP] = CB(21 + i, 0); pg[(size_t)(6 + i) * MP] = CB(i, 0); }
-            pg[(size_t)9 * MP] = CB(24, 0);
-        }
-        nout = 1;
-    } else {
-        for (int base = 0, r = 0; base < ncon; base += G::BT, ++r) {
-            const int k = base + tid;
-            // beyond 32 rounds (more than 32 x group size contacts: a level-set face lying flat) the bit mask is full and the
-            // state array, which such a count keeps in global memory, is read instead
-#if DSS_ALL_SHAPES
-            const int flag = (k < ncon) && (r < 32 ? (int)((keptbits >> r) & 1u) : (cstate[k] == 2));
-#else
-            const int flag = (k < ncon) && ((keptbits >> r) & 1u);     // (the lean variant stops at HCAP contacts per cluster)
-#endif
-            if (!G::any(flag)) continue;
-            const int slot = compact_slot(flag, nout, S);
-            if (slot >= 0 && slot < MP) {
-                pf[slot] = kface[k];
-                for (int i = 0; i < 3; ++i) {
-                    pabc[(size_t)i * MP + slot] = CB(15 + i, k);
-                    pg[(size_t)i * MP + slot] = CB(18 + i, k); pg[(size_t)(3 + i) * MP + slot] = CB(21 + i, k); pg[(size_t)(6 + i) * MP + slot] = CB(i, k);
-                }
-                pg[(size_t)9 * MP + slot] = CB(24, k);
-            }
-        }
-        if (nout > MP) { over |= 4; nout = MP; }
-    }
-    if (tid == 0) { *pc_count = nout; if (over) atomicOr(W.overflow + sc, over); }
-    STAMP(6);
-    return 0;
+#include "np_filter_emit.inc"
 #undef STAMP
 #undef CB
 }
@@ -1292,6 +664,7 @@ static inline int np_grid(int B, int nb)
 }
 // enqueue detection at the current pose; results land in (nc_out, body_out, ...)
 #if DSS_ALL_SHAPES
+int launch_igr_rounds(const DssWorld &W, hipStream_t stream);   // narrowphase_igr.hip
 int launch_find_contacts_all(const DssWorld &W, int *nc_out, int *body_out, int *face_out, double *abc_out,
                              double *geom_out, hipStream_t stream)
 {
@@ -1310,13 +683,16 @@ int launch_find_contacts(const DssWorld &W, int *nc_out, int *body_out, int *fac
         return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
     }
     const int nup = W.nb * (W.nb - 1) / 2, np = W.nb * (W.nb - 1);
-    (void)hipMemsetAsync(W.n_pairs, 0, 6 * sizeof(int), stream);   // counts and cursors of the three lists
+    (void)hipMemsetAsync(W.n_pairs, 0, 8 * sizeof(int), stream);   // counts and cursors of the work lists
     hipLaunchKernelGGL(overlap_kernel, dim3(W.B), dim3(OV_NT), 0, stream, W);
     // 256 CUs x DSS_NP_WAVES resident workgroups walk the work lists; no idle dispatches
     const int grid = np_grid(W.B, W.nb);
     hipLaunchKernelGGL(narrowphase_kernel<false>, dim3(grid), dim3(NT), 0, stream, W);
     // normally finds an empty list: a small grid keeps the empty launch cheap, and works a real list off all the same
     hipLaunchKernelGGL(narrowphase_kernel<true>, dim3(grid < 64 ? grid : 64), dim3(NT), 0, stream, W);
+#if DSS_ALL_SHAPES
+    if (W.igr_list) { const int rc = launch_igr_rounds(W, stream); if (rc) return rc; }
+#endif
     hipLaunchKernelGGL(compact_contacts_kernel, dim3(W.B), dim3(64), 0, stream, W, nc_out, body_out, face_out, abc_out, geom_out);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }

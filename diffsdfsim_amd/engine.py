@@ -60,7 +60,7 @@ def default_vgrad(shape_type, prm, verts):
     Box: only coordinates that ARE +-dims/2 carry a gradient (the reference re-ties the linspace ends),
     d v_k / d dims_k = sign/2.  Sphere: verts = unit * rad, d v / d rad = v / rad."""
     verts = np.asarray(verts, np.float64)
-    if shape_type in (abi.SHAPE_BOX_ROUNDED, abi.SHAPE_BRICK, abi.SHAPE_BOWL):
+    if shape_type in (abi.SHAPE_BOX_ROUNDED, abi.SHAPE_BRICK, abi.SHAPE_BOWL, abi.SHAPE_IGR):
         return np.zeros_like(verts)   # level-set / two-parameter meshes: no per-vertex parameter tangent in this layout
     if shape_type == abi.SHAPE_BOX:
         hd = np.asarray(prm, np.float64)[:3] / 2
@@ -130,10 +130,26 @@ class BatchEngine:
         mt = mesh_table(spec["meshes"], vg)
         shapes = abi.array_shapes(B, nb, neq, maxc, fric_dirs, max_cand, max_pc, max_sub, len(spec["meshes"]),
                                   len(mt["verts"]), len(mt["faces"]), len(mt["fch_box"]), len(mt["vch_box"]))
+        # neural SDF bodies (shape_type 6): network weights + the scratch of the round-based narrow phase
+        st_all = np.asarray(spec["shape_type"]).reshape(B, nb)
+        igr_b = st_all == abi.SHAPE_IGR
+        self.igr_items_cap = self.igr_qcap = 0
+        if igr_b.any():
+            if spec.get("igr_net") is None:
+                raise ValueError("a body of shape_type SHAPE_IGR needs spec['igr_net'] (diffsdfsim_amd.igr.pack_weights)")
+            nocon = np.asarray(spec.get("no_contact", np.zeros((nb, nb))), bool)
+            per_scene = [sum(2 for i in range(nb) for j in range(i + 1, nb) if (row[i] or row[j]) and not nocon[i, j]) for row in igr_b]
+            self.igr_items_cap = max(1, int(sum(per_scene)))
+            self.igr_qcap = int(spec.get("igr_qcap", min(self.igr_items_cap * 4096, 1 << 24)))
+            shapes.update(abi.igr_shapes(self.igr_items_cap, self.igr_qcap, max_cand))
         kinds = dict(abi.FIELDS)
         self.arr = {}
         for name, shp in shapes.items():
             self.arr[name] = self.be.zeros(shp, abi.NP_DTYPE[kinds[name]])
+        if igr_b.any():
+            for k in ("W0", "b0", "Wp", "bh", "W8", "b8"):
+                w = spec["igr_net"][k]
+                self.arr["igr_" + k] = w if not isinstance(w, np.ndarray) and hasattr(w, "data_ptr") else self.be.from_numpy(np.asarray(w, np.float64))
         host = dict(mt)
         host.update(pose=pose, vel=spec["vel"], mass=spec["mass"], inertia=np.asarray(spec["inertia"]).reshape(B, nb, 9),
                     restitution=spec["restitution"], fric=spec["fric"], fext=spec["fext"], shape_type=spec["shape_type"],
@@ -156,7 +172,7 @@ class BatchEngine:
         # points, clusters of thousands of contacts).  Full when a rare primitive or a dense mesh on a free body exists.
         full = spec.get("full_kernels")
         if full is None:
-            full = bool((np.asarray(spec["shape_type"]) > abi.SHAPE_CYLINDER).any())
+            full = bool((np.asarray(spec["shape_type"]) > abi.SHAPE_CYLINDER).any())      # (includes neural bodies)
             mid = np.asarray(spec["mesh_id"]).reshape(B, nb)
             for b in range(nb):
                 pinned = neq >= 6 and (np.abs(Je[0][:, 6 * b:6 * b + 6]).sum(axis=1) > 0).sum() >= 6
@@ -164,6 +180,7 @@ class BatchEngine:
                     full = True
         W.shape_rare = int(bool(full))
         W.max_sub = max_sub
+        W.igr_items_cap, W.igr_qcap, W.igr_rounds = self.igr_items_cap, self.igr_qcap, int(spec.get("igr_rounds", 0))
         for name, kind in abi.FIELDS:
             if kind in ("pd", "pi", "pb"):
                 setattr(W, name, self.be.ptr(self.arr[name]) if name in self.arr else None)
@@ -228,7 +245,8 @@ class BatchEngine:
         ov = self.get("overflow")
         s = int(np.nonzero(ov)[0][0])
         names = [n for b, n in ((1, "max_cand"), (2, "more than 1024 moving Frank-Wolfe candidates -- or, with the lean kernels (spec['full_kernels'] unset/False), "
-                                         "contacts of one normal cluster -- in a body pair"), (4, "max_pc"), (8, "maxc"), (16, "max_sub (tape slots for the backward pass)")) if ov[s] & b]
+                                         "contacts of one normal cluster -- in a body pair"), (4, "max_pc"), (8, "maxc"), (16, "max_sub (tape slots for the backward pass)"),
+                                        (32, "igr_qcap (query list of the neural narrow phase)"), (64, "igr_rounds")) if ov[s] & b]
         raise RuntimeError("contact detection exceeded a capacity in scene %d (%s): raise the limit when constructing "
                            "the engine / world -- contacts were dropped, the step is not valid" % (s, ", ".join(names)))
 

@@ -47,3 +47,55 @@ def igr_query(pts, latent, P, wrt="xyz"):
                          _lib.ptr(grad), _lib.stream_ptr(pts.device))
     _lib.check(rc, "dss_igr_query")
     return sdf, grad
+
+
+def weights_from_module(network):
+    """(Ws, bs) of an IGR ``ImplicitNet``-like torch module: attributes ``lin0 .. lin8`` (torch.nn.Linear), as the
+    external IGR repository defines it and the reference loads it (`utils.py:300-320`).  Only the bob_spot_setup shape
+    (IGR_data/train_configs/bob_spot_setup.conf:38-45: input 2 + 3, eight hidden layers of 128, skip at layer 4) runs on
+    the device kernels."""
+    Ws, bs = [], []
+    for l in range(9):
+        lin = getattr(network, "lin%d" % l, None)
+        if lin is None:
+            raise ValueError("decode_igr needs an ImplicitNet with layers lin0..lin8 (got %r)" % type(network))
+        Ws.append(lin.weight.detach().cpu().double().numpy())
+        bs.append(lin.bias.detach().cpu().double().numpy())
+    if getattr(network, "lin9", None) is not None or Ws[0].shape != (H, 5) or Ws[8].shape != (1, H) or Ws[3].shape != (H - 5, H):
+        raise NotImplementedError("only the 5 -> 8 x 128 -> 1 network with a skip connection into layer 4 is built for the device")
+    return Ws, bs
+
+
+class IgrNet:
+    """A network on the device: packed weights for the kernels + the plain layers (host) for reference."""
+
+    def __init__(self, Ws, bs, device="cuda"):
+        self.Ws, self.bs = Ws, bs
+        self.packed = pack_weights(Ws, bs, device)
+
+    @classmethod
+    def from_module(cls, network, device="cuda"):
+        hit = getattr(network, "_dss_igr_net", None)
+        if hit is None:
+            hit = cls(*weights_from_module(network), device=device)
+            try:
+                network._dss_igr_net = hit       # pack once per network object
+            except Exception:
+                pass
+        return hit
+
+
+def decode_igr(network):
+    """`decode_igr` (`sdf_physics/physics3d/utils.py:330-350`): network -> ``sdf(pts, latent)``.  The returned function
+    evaluates on the device (dss_igr_query) and carries the packed network (``.igr``), which is how ``SDF3D`` recognises a
+    neural SDF it can hand to the stepper's kernels."""
+    net = network if isinstance(network, IgrNet) else IgrNet.from_module(network)
+
+    def sdf(pts, latent, max_batch=32 ** 3):
+        dev = net.packed["W0"].device
+        p = torch.as_tensor(pts, dtype=torch.float64).to(dev).contiguous()
+        lat = torch.as_tensor(latent, dtype=torch.float64).detach().to(dev).contiguous()
+        return igr_query(p, lat, net.packed)[0]
+
+    sdf.igr = net
+    return sdf

@@ -257,6 +257,63 @@ class SDFBowl(Body3D):
         return self._mesh_ang_inertia(mass)
 
 
+class SDF3D(Body3D):
+    """`sdf_physics/physics3d/bodies.py:627-760`: a body given by an SDF function over its unit cube, ``scale`` mapping
+    the cube to world units -- ``SDF3D(pos, scale, sdf_func=decode_igr(network), params=[latent])`` as in
+    demos/demo_meshsdf.py:136.  On the device path the function must be a neural SDF made by ``decode_igr`` (the network
+    runs on the matrix cores inside the stepper); the analytic primitives have their own classes.  Mesh: level set of the
+    network on 128^3 (MeshSDF, differentiable w.r.t. the latent code); inertia from the mesh."""
+    shape_type = abi.SHAPE_IGR
+
+    def __init__(self, pos, scale, sdf_func, params, grad_func=None, vel=(0, 0, 0, 0, 0, 0), mass=1,
+                 restitution=Defaults3D.RESTITUTION, fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, res=128, **kw):
+        net = getattr(sdf_func, "igr", None)
+        if net is None or grad_func is not None:
+            raise NotImplementedError("SDF3D on the device path takes sdf_func=decode_igr(network) (a neural SDF the kernels "
+                                      "can evaluate); arbitrary Python SDF functions cannot run inside the HIP stepper")
+        if len(params) != 1 or torch.as_tensor(params[0]).numel() != 2:
+            raise NotImplementedError("decode_igr networks with a 2-dimensional latent code (bob_spot_setup) are built")
+        self.igr = net
+        self.sdf_func, self.params = sdf_func, params
+        self.latent = get_tensor(params[0])
+        self.scale = get_tensor(scale)
+        v, f = meshsdf.igr_mesh(self.latent, net.packed, res=res)
+        self.verts_t = v * self.scale.to(v.device)
+        self.verts_np = self.verts_t.detach().cpu().numpy()
+        self.faces_np = f.cpu().numpy().astype(np.int64)
+        self.vgrad_np = np.zeros_like(self.verts_np)
+        super().__init__(pos, vel, mass, restitution, fric_coeff, eps, **kw)
+
+    verts = property(lambda self: torch.as_tensor(self.verts_np))
+    faces = property(lambda self: torch.as_tensor(self.faces_np))
+
+    def shape_prm(self):
+        return torch.cat([self.latent.reshape(2).to(torch.float64), self.latent.new_zeros(1).to(torch.float64)])
+
+    def shape_aux(self):
+        return float(self.scale.detach())
+
+    def query_sdfs(self, pts_loc, return_grads=True, return_overlapmask=False):
+        """bodies.py:721-760 with the network on the device: values scaled, gradients normalised, outside the query cube
+        phi = scale and grad = 0."""
+        from ..igr import igr_query
+        dev = self.igr.packed["W0"].device
+        pts = torch.as_tensor(pts_loc, dtype=torch.float64).to(dev)
+        sc = float(self.scale.detach())
+        mask = (pts.abs() <= sc).all(dim=1)
+        sdf = torch.full((pts.shape[0],), sc, dtype=torch.float64, device=dev)
+        grad = torch.zeros_like(pts)
+        if bool(mask.any()):
+            phi, g = igr_query((pts[mask] / sc).contiguous(), self.latent.detach().to(dev), self.igr.packed)
+            sdf[mask] = phi * sc
+            grad[mask] = g / g.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        out = (sdf,) + ((grad,) if return_grads else ()) + ((mask,) if return_overlapmask else ())
+        return out if len(out) > 1 else out[0]
+
+    def _get_ang_inertia(self, mass):
+        return self._mesh_ang_inertia(mass)
+
+
 class SDFGrid3D(Body3D):
     """`sdf_physics/physics3d/bodies.py:763-775`: the SDF is a voxel grid ``sdf`` [n,n,n] over the body's unit cube
     (``scale`` maps it to world units).  Mesh: marching cubes of the grid itself at its own resolution; inertia from

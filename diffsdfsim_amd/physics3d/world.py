@@ -177,6 +177,11 @@ class World3D(BatchWorld3D):
                     shape_aux=np.array([[b.shape_aux() for b in bodies]], np.float64),
                     mesh_id=np.arange(nb, dtype=np.int32)[None], meshes=[(b.verts_np, b.faces_np) for b in bodies],
                     mesh_vgrad=[b.vgrad_np for b in bodies], Je=Je, no_contact=nocon)
+        nets = {id(b.igr): b.igr for b in bodies if getattr(b, "igr", None) is not None}
+        if len(nets) > 1:
+            raise NotImplementedError("all neural SDF bodies of a world share one network (one decode_igr(network))")
+        if nets:
+            spec["igr_net"] = next(iter(nets.values())).packed
         maxc = 32 * max(1, nb - 1)
         # level-set meshes (128^3 marching cubes, triangles of ~1/64 of the body's size) put thousands of faces within
         # eps of a flat neighbour: give the Frank-Wolfe working set room for them

@@ -9,7 +9,7 @@ import numpy as np
 
 CAND_FIELDS = 28
 N_ACTIVE_OVERFLOW = 1 << 30
-SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_BOX_ROUNDED, SHAPE_BRICK, SHAPE_BOWL = 0, 1, 2, 3, 4, 5
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_BOX_ROUNDED, SHAPE_BRICK, SHAPE_BOWL, SHAPE_IGR = 0, 1, 2, 3, 4, 5, 6
 
 _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
@@ -40,7 +40,13 @@ FIELDS = [
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
     ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"), ("tp_flags", "pi"),
     ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("ev_np_start", "ev"), ("ev_np_stop", "ev"), ("dbg_stamps", "ev"),
+    # neural SDF bodies: DssIgrNet (six pointers), capacities, the round-based narrow phase's item state and query lists
+    ("igr_W0", "pd"), ("igr_b0", "pd"), ("igr_Wp", "pd"), ("igr_bh", "pd"), ("igr_W8", "pd"), ("igr_b8", "pd"),
+    ("igr_items_cap", "i"), ("igr_qcap", "i"), ("igr_rounds", "i"),
+    ("igr_list", "pi"), ("igr_hdr", "pi"), ("igr_cface", "pi"), ("igr_cstate", "pi"), ("igr_cbuf", "pd"),
+    ("igr_qpts", "pd"), ("igr_qlat", "pi"), ("igr_qtag", "pi"), ("igr_qsdf", "pd"), ("igr_qgrad", "pd"), ("igr_qn", "pi"),
 ]
+IGR_HDR, IGR_ROUNDS = 16, 42
 
 
 class DssWorld(ctypes.Structure):
@@ -53,6 +59,16 @@ NP_DTYPE = {"pd": np.float64, "pi": np.int32, "pb": np.uint8}
 def np_slots(B, nb):
     """Scratch slots of the persistent narrow phase = wavefronts of its grid (mirrors dss_np_slots)."""
     return 4 * min(B * nb * (nb - 1), 256 * 3)
+
+
+def igr_shapes(items_cap, qcap, max_cand):
+    """Arrays of the round-based narrow phase for neural SDF bodies (narrowphase_igr.hip)."""
+    return {
+        "igr_list": (items_cap,), "igr_hdr": (items_cap, IGR_HDR), "igr_cface": (items_cap, 3, max_cand),
+        "igr_cstate": (items_cap, max_cand), "igr_cbuf": (items_cap, CAND_FIELDS, max_cand),
+        "igr_qpts": (4, qcap, 3), "igr_qlat": (4, qcap), "igr_qtag": (4, qcap), "igr_qsdf": (4, qcap), "igr_qgrad": (2, qcap, 3),
+        "igr_qn": (2 * (IGR_ROUNDS + 2),),
+    }
 
 
 def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF, NFC=1, NVC=1):
@@ -75,7 +91,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
         "pose0": (B, nb, 7), "vel0": (B, nb, 6),
         "Mblk": (B, nb, 6, 6), "pvec": (B, nz), "cop": (B, NFc, maxc), "x": (B, nz), "lam": (B, NR, maxc),
         "slack": (B, NR, maxc), "nu": (B, max(neq, 1)), "cop_body": (B, 2, maxc), "lcp_iters": (B,), "lcp_status": (B,),
-        "ovl": (B, nb, nb), "pair_list": (3 * B * npair,), "n_pairs": (6,), "invalid": (B,), "overflow": (B,),
+        "ovl": (B, nb, nb), "pair_list": (3 * B * npair,), "n_pairs": (8,), "invalid": (B,), "overflow": (B,),
         "pc_count": (B, npair), "pc_stats": (B, npair, 2), "pc_face": (B, npair, max_pc), "pc_abc": (B, npair, 3, max_pc),
         "pc_geom": (B, npair, 10, max_pc),
         "cand_face": (np_slots(B, nb), 2, max_cand), "cand_state": (np_slots(B, nb), max_cand),

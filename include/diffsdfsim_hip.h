@@ -110,6 +110,13 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
  * the caller.  One "attempt" = solve -> integrate -> detect -> accept/halve for every active
  * scene (the reference's retry loop, world.py:249-356, run in lock step across the batch).
  * ------------------------------------------------------------------------------------ */
+/* The nine Linear layers of the IGR network (decode_igr, utils.py:330-350) in the layout the matrix-core kernel reads:
+ * W0 [128][5], b0 [128]; Wp = the seven 128x128 layers in MFMA fragment order (dss_igr_packed_doubles() doubles,
+ * diffsdfsim_amd/igr.py: pack_weights; layer 3's five missing rows are zero), bh [7][128]; W8 [128], b8 [1]. */
+typedef struct DssIgrNet {
+    const double *W0, *b0, *Wp, *bh, *W8, *b8;
+} DssIgrNet;
+
 typedef struct DssWorld {
     /* sizes */
     int B, nb, neq, maxc, fric_dirs;
@@ -168,10 +175,10 @@ typedef struct DssWorld {
     int *ovl;                /* [B][nb][nb] overlap flags */
     int *pair_list;          /* [3][B*npairs] active (scene*npairs + directed pair) work items of this attempt:
                                 workgroup items, wavefront items, wavefront items deferred to a workgroup */
-    int *n_pairs;            /* [6]: workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
+    int *n_pairs;            /* [8] (index 6 = length of the neural work list igr_list): workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
                                 work cursors, deferred-list length and cursor */
     int *invalid;            /* [B] penetration > tol found in this attempt */
-    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc, 16 max_sub (tape slots) */
+    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc, 16 max_sub (tape slots), 32 igr_qcap / igr_items_cap, 64 igr_rounds */
     int *pc_count;           /* [B][npairs] */
     int *pc_stats;           /* [B][npairs][2] work done for the pair: face runs tested, candidate faces (bench accounting) */
     int *pc_face;            /* [B][npairs][max_pc] */
@@ -190,6 +197,25 @@ typedef struct DssWorld {
     void *ev_np_start, *ev_np_stop;   /* same, around the contact-detection launches */
     /* optional [grid of narrowphase][8] phase time stamps (diagnostic runs only; NULL in production) */
     long long *dbg_stamps;
+    /* ---- neural SDF bodies (shape_type DSS_SHAPE_IGR; SDF3D(sdf_func=decode_igr(net), params=[latent]), bodies.py:627-760):
+       shape_prm[0..1] = the body's latent code, shape_aux = its scale.  A directed pair with a neural body is a work item of
+       the round-based narrow phase (narrowphase_igr.hip): items advance from one batch of SDF queries to the next, the
+       queries of all items are evaluated together on the matrix cores (igr_mlp.hip).  All NULL / 0 without such bodies. */
+    DssIgrNet igr;
+    int igr_items_cap;       /* item slots: >= B * (directed pairs with a neural body) */
+    int igr_qcap;            /* points per query list */
+    int igr_rounds;          /* query rounds per detection (0 = the default that covers every stage) */
+    int *igr_list;           /* [igr_items_cap] work items (scene * npairs + directed pair) of this detection */
+    int *igr_hdr;            /* [igr_items_cap][DSS_IGR_HDR] state of every item between rounds */
+    int *igr_cface;          /* [igr_items_cap][3][max_cand] candidate faces / contact faces / query ranks */
+    int *igr_cstate;         /* [igr_items_cap][max_cand] */
+    double *igr_cbuf;        /* [igr_items_cap][DSS_CAND_FIELDS][max_cand] */
+    double *igr_qpts;        /* [4][igr_qcap][3] query points in the network's unit frame: (buffer set, value | gradient list) */
+    int *igr_qlat;           /* [4][igr_qcap] scene * nb + body of the latent code */
+    int *igr_qtag;           /* [4][igr_qcap] what the item wants back with the answer (the face id of a candidate test) */
+    double *igr_qsdf;        /* [4][igr_qcap] network outputs */
+    double *igr_qgrad;       /* [2][igr_qcap][3] d phi / d xyz of the gradient lists */
+    int *igr_qn;             /* [2 (DSS_IGR_ROUNDS + 2)] list lengths: value and gradient list of every round */
 } DssWorld;
 
 #define DSS_N_ACTIVE_OVERFLOW (1 << 30)   /* set in n_active[0] once any scene's overflow word is non-zero */
@@ -201,6 +227,9 @@ typedef struct DssWorld {
 #define DSS_SHAPE_BOX_ROUNDED 3 /* SDFBoxRounded (bodies.py:857-870): shape_prm = outer dims, shape_aux = r */
 #define DSS_SHAPE_BRICK 4      /* SDFBrick (bodies.py:873-885): shape_prm = dims, shape_aux = r (x-y corners rounded) */
 #define DSS_SHAPE_BOWL 5       /* SDFBowl (bodies.py:1013-1027): shape_prm = (r, d, -), opening towards +z */
+#define DSS_SHAPE_IGR 6        /* SDF3D with decode_igr (bodies.py:627-760, utils.py:330-350): shape_prm = latent code (2), shape_aux = scale */
+#define DSS_IGR_HDR 16         /* ints of per-item state of the round-based narrow phase */
+#define DSS_IGR_ROUNDS 42      /* query rounds that cover every stage: candidates 2, Frank-Wolfe 1 + 31, projection 2, geometry 4, spare */
 
 size_t dss_world_sizeof(void);
 /* scratch slots the narrow phase needs for a batch of B scenes with nb bodies (sizes cand_face/cand_state/cand_buf) */
@@ -261,6 +290,15 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream);
  * zero), bh [7][128]; W8 [128], b8 [1].  Outputs sdf [n] and d sdf / d xyz [n][3] (not normalised).
  * ------------------------------------------------------------------------------------ */
 size_t dss_igr_packed_doubles(void);
+/* what a query round evaluates per point */
+#define DSS_IGR_XYZ 0      /* phi and d phi / d xyz (SDF3D.query_sdfs with return_grads, bodies.py:730-745) */
+#define DSS_IGR_LATENT 1   /* phi and d phi / d latent (MeshSDF backward, bodies.py:680-702; the stepper's latent adjoint) */
+#define DSS_IGR_VALUE 2    /* phi only (return_grads=False: candidate test, Laplacian probes, contacts.py:46-60, 184-196) */
+/* One evaluation round over a point list: pts [n][3] in the network's unit frame, point i uses the latent code
+ * latents[lat_idx[i] * lat_stride + 0..1] (lat_idx NULL: code 0).  The list length is *n_dev if n_dev is non-NULL (device
+ * memory, at most n_cap), else n_cap.  sdf [n]; grad [n][3] (unused for DSS_IGR_VALUE). */
+int dss_igr_query_list(const DssIgrNet *net, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
+                       const int *n_dev, int n_cap, int mode, double *sdf, double *grad, void *stream);
 int dss_igr_query(const double *pts, const double *latent, const double *W0, const double *b0, const double *Wp,
                   const double *bh, const double *W8, const double *b8, int n, double *sdf, double *grad, void *stream);
 /* Same evaluation, tangents on the latent code: grad [n][3] = (d sdf / d latent_0, d sdf / d latent_1, 0). */

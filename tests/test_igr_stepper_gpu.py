@@ -1,0 +1,50 @@
+"""GPU: a NEURAL SDF body inside the batched stepper (BASELINE configs[3], demos/demo_meshsdf.py) against rollouts recorded
+from the reference's own ``SDF3D.query_sdfs`` / ``FWContactHandler`` / ``World3D`` with a seeded stand-in network
+(oracle/gen/gen_igr_golden.py; the trained IGR weights are not available offline, so the network itself stays
+parity-unpinned -- the STEPPER around it is pinned here).
+
+north_star tolerance: contact-pair indices exact, positions / velocities / gradients 1e-5 relative."""
+import numpy as np
+import pytest
+
+import igr_helpers as H
+import rollout_helpers as R
+
+pytestmark = pytest.mark.gpu
+
+
+def run_like_run_world(E, g):
+    """`run_world`'s loop (physics3d/world.py:113-205): world.step() -- one step_dt each -- until t >= run_time."""
+    n = 0
+    while float(E.get("t")[0]) < float(g["run_time"]):
+        E.step_once()
+        n += 1
+        assert n < 500
+    return n
+
+
+@pytest.mark.parametrize("name", ["rollout_igr_small", "rollout_igr_demo"])
+def test_neural_body_rollout_matches_reference(name):
+    from diffsdfsim_amd.engine import BatchEngine
+    g = R.load_rollout(name)
+    E = BatchEngine(H.spec_from_golden(g, 2), **H.engine_kwargs(g, max_sub=128))
+    assert int(E.get("overflow").max()) == 0
+    R.check_contacts(E, 0, g["init_body"], g["init_geom"], len(g["init_body"]))
+    run_like_run_world(E, g)
+    assert int(E.get("overflow").max()) == 0
+    nsub = E.get("nsub")
+    assert (nsub == len(g["traj_t"])).all(), (nsub, len(g["traj_t"]))
+    k = len(g["traj_t"]) - 1
+    pose, vel = E.get("pose"), E.get("vel")
+    tp, tnc, tb = E.get("tp_pose"), E.get("tp_nc"), E.get("tp_body")
+    # every step of the way: start poses of sub-step j+1 = the reference's poses after sub-step j; same contact pairs
+    for j in range(1, k + 1):
+        assert np.abs(tp[j, 0] - g["traj_p"][j - 1]).max() < 1e-7, j
+        n = int(g["traj_nc"][j - 1])
+        assert int(tnc[j, 0]) == n, (j, int(tnc[j, 0]), n)
+        assert [tuple(r) for r in tb[j, 0][:, :n].T] == [tuple(r) for r in g["traj_body"][j - 1][:n]], j
+    scale = max(1.0, np.abs(g["traj_p"][k]).max())
+    assert np.abs(pose[0] - g["traj_p"][k]).max() < 1e-7 * scale and np.abs(vel[0] - g["traj_v"][k]).max() < 1e-6
+    assert (pose == pose[:1]).all() and (vel == vel[:1]).all(), "replicated scenes diverged"
+    for s in (0, 1):
+        R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
