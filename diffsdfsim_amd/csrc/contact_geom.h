@@ -26,6 +26,7 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
     sd.scale = val(s.scale);
 #if DSS_ALL_SHAPES
     sd.hr = val(s.hr);
+    sd.lin = nullptr;
 #endif
     double acc = 0.0, pt[3] = {val(p[0]), val(p[1]), val(p[2])}, g[3];
     for (int i = 0; i < 3; ++i) {
@@ -52,6 +53,15 @@ __host__ __device__ inline void contact_head(const BodyG<T> &b1, const T tri[3][
 {
     for (int i = 0; i < 3; ++i) cp1[i] = tri[0][i] * abc[0] + tri[1][i] * abc[1] + tri[2][i] * abc[2];
     // the triangle point is pulled onto body 1's true surface by one Newton step (contacts.py:169-171)
+#if DSS_ALL_SHAPES
+    if (b1.shape.type == SHAPE_IGR) {      // (reverse sweep only: records 0 and 1 of the body's queries for this contact)
+        igr_lin(b1.shape, 0, cp1, d1, n1);
+        for (int i = 0; i < 3; ++i) cp1[i] = cp1[i] - d1 * n1[i];
+        igr_lin(b1.shape, 1, cp1, d1, n1);
+        quat_apply(b1.q, cp1, p1);
+        return;
+    }
+#endif
     query_sdf(b1.shape, cp1, d1, n1, true);
     for (int i = 0; i < 3; ++i) cp1[i] = cp1[i] - d1 * n1[i];
     query_sdf(b1.shape, cp1, d1, n1, true);
@@ -64,6 +74,10 @@ __host__ __device__ inline void contact_tail(const BodyG<T> &b1, const BodyG<T> 
     T cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
     for (int i = 0; i < 3; ++i) { cpw[i] = p1[i] + b1.pos[i]; rel[i] = cpw[i] - b2.pos[i]; }
     quat_apply_inv(b2.q, rel, cp2);
+#if DSS_ALL_SHAPES
+    if (b2.shape.type == SHAPE_IGR) igr_lin(b2.shape, 0, cp2, d2, n2);
+    else
+#endif
     query_sdf(b2.shape, cp2, d2, n2, true);
     bool stable;
     if (stable_io && *stable_io >= 0) stable = *stable_io != 0;

@@ -296,6 +296,9 @@ template <class T> struct Shape {
     T hd[3];    // unit-frame constants hoisted out of the queries (invariant per body), see make_shape
 #if DSS_ALL_SHAPES
     T hr;       // rounded box / brick: corner radius / scale
+    // neural SDF (SHAPE_IGR) in the reverse sweep: records of the network's value and derivatives at the points this body is
+    // queried at for ONE contact (igr_lin below), evaluated beforehand on the matrix cores; NULL elsewhere
+    const double *lin;
 #endif
 };
 // aux: the corner radius r of SDFBoxRounded / SDFBrick (a constant of the body; bodies.py:857-885), unused otherwise
@@ -305,6 +308,7 @@ template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int t
     for (int i = 0; i < 3; ++i) s.prm[i] = prm[i];
 #if DSS_ALL_SHAPES
     s.hr = T(0.0);
+    s.lin = nullptr;
 #endif
     if (type == SHAPE_BOX) {
         s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
@@ -346,6 +350,7 @@ template <class T> __host__ __device__ inline void make_unit_shape(Shape<T> &s, 
     for (int i = 0; i < 3; ++i) { s.prm[i] = pu[i]; s.hd[i] = T(0.0); }
     s.scale = T(1.0);
     s.hr = au;
+    s.lin = nullptr;
     if (type == SHAPE_BOX) for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0;          // box_sdf: half_dims = dims / 2
     else if (type == SHAPE_BOX_ROUNDED) for (int i = 0; i < 3; ++i) s.hd[i] = (pu[i] - au * 2.0) / 2.0;
     else if (type == SHAPE_BRICK) { for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0; s.hd[0] = s.hd[0] - au; s.hd[1] = s.hd[1] - au; }
@@ -484,6 +489,23 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
         if (want_grad) { T g1[3]; normalize(p, g1); normalize(g1, g); }
     }
 }
+
+#if DSS_ALL_SHAPES
+// A neural SDF body's query as the reference's autograd sees it (SDF3D.query_sdfs, bodies.py:727-745: the input gradient is
+// taken WITHOUT create_graph, so the normal is a constant; the value keeps the graph to the point and to the latent code):
+//   phi(pt, latent) = phi0 + raw . (pt - pt0) + dlat . (latent - latent0),   g = nrm   (constant)
+// record `rec` of s.lin: phi0, raw[3] = d phi / d pt, dlat[2] = d phi / d latent (both in world units), nrm[3].
+constexpr int IGR_LIN = 9;
+template <class T> __host__ __device__ inline void igr_lin(const Shape<T> &s, int rec, const T *pt, T &phi, T *g)
+{
+    const double *r = s.lin + IGR_LIN * rec;
+    T acc = T(r[0]);
+    for (int i = 0; i < 3; ++i) acc = acc + (pt[i] - val(pt[i])) * r[1 + i];
+    for (int j = 0; j < 2; ++j) acc = acc + (s.prm[j] - val(s.prm[j])) * r[4 + j];
+    phi = acc;
+    for (int i = 0; i < 3; ++i) g[i] = T(r[6 + i]);
+}
+#endif
 
 // SDF3D.query_sdfs: outside the [-scale, scale]^3 box: phi = scale, grad = 0
 template <class T> __host__ __device__ inline bool query_sdf(const Shape<T> &s, const T *pt, T &phi, T *g, bool want_grad)

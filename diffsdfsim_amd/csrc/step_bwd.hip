@@ -34,7 +34,7 @@ struct SlotView {   // where the data of "sub-step k" and of "the state after it
     const double *pose_n;                       // [nb][7] pose after sub-step k
     double dt;
     int nc_k; const int *body_k; const double *geom_k;                   // contacts used by the LCP of k
-    int nc_n; const int *body_n, *face_n; const double *abc_n;           // contacts detected after k
+    int nc_n; const int *body_n, *face_n; const double *abc_n, *geom_n;  // contacts detected after k
     const double *x, *lam, *slack, *nu;
 };
 
@@ -56,10 +56,31 @@ __device__ inline void view_slot(const DssWorld &W, int sc, int k, SlotView &v)
         const size_t r2 = (size_t)(k + 1) * W.B + sc;
         v.pose_n = W.tp_pose + r2 * nb * 7;
         v.nc_n = W.tp_nc[r2]; v.body_n = W.tp_body + r2 * 2 * MX; v.face_n = W.tp_face + r2 * MX; v.abc_n = W.tp_abc + r2 * 3 * MX;
+        v.geom_n = W.tp_geom + r2 * 10 * MX;
     } else {
         v.pose_n = W.pose + (size_t)sc * nb * 7;
         v.nc_n = W.nc[sc]; v.body_n = W.c_body + (size_t)sc * 2 * MX; v.face_n = W.c_face + (size_t)sc * MX;
         v.abc_n = W.c_abc + (size_t)sc * 3 * MX;
+        v.geom_n = W.c_geom + (size_t)sc * 10 * MX;
+    }
+}
+
+// which sub-step a scene undoes in this call, and the view of it (shared by the kernels of one dss_step_backward)
+__device__ inline void bwd_select(const DssWorld &W, const DssAdjoint &A, int sc, int &k, int &act, int &init, SlotView &v)
+{
+    const int nb = W.nb, MX = W.maxc;
+    k = A.cur_slot[sc];
+    act = (k >= 0 && k >= A.lo_slot[sc] && k < W.nsub[sc] && k < W.max_sub);   // (a slot beyond the tape was never recorded)
+    // slot -1 = the contacts found at construction (World.__init__, world.py:96): only their geometry
+    // adjoint is left to push onto the initial pose and the shape parameters
+    init = (k == -1 && A.lo_slot[sc] <= -1 && W.nsub[sc] > 0);
+    if (init) {
+        const size_t r0 = (size_t)sc;   // tape slot 0
+        v.pose_n = W.tp_pose + r0 * nb * 7;
+        v.nc_n = W.tp_nc[r0]; v.body_n = W.tp_body + r0 * 2 * MX; v.face_n = W.tp_face + r0 * MX; v.abc_n = W.tp_abc + r0 * 3 * MX;
+        v.geom_n = W.tp_geom + r0 * 10 * MX;
+    } else if (act) {
+        view_slot(W, sc, k, v);
     }
 }
 
@@ -68,8 +89,11 @@ __device__ inline void view_slot(const DssWorld &W, int sc, int k, SlotView &v)
 // SDF queries and the Newton step): they take two full passes.  q2, x2 and prm2 enter the body-2 half alone
 // (contact_tail: one query, two rotations), so their three passes differentiate that half with the head as constants;
 // x1 appears only in rel = p1 + x1 - x2, hence d/dx1 = -d/dx2 and needs no pass of its own.
+// lin1 / lin2: igr_lin records of a neural body 1 / body 2 for this contact (NULL: analytic body); stable_in >= 0: which
+// body's normal the contact used, decided by the caller (for neural bodies the Laplacian probes are not repeated).
 __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
-                            const double *abc, const double *gbar, double *out, double *g_verts)
+                            const double *abc, const double *gbar, double *out, double *g_verts,
+                            const double *lin1 = nullptr, const double *lin2 = nullptr, int stable_in = -1)
 {
     constexpr int N = 4;
     typedef Dual<N> D;
@@ -89,7 +113,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     for (int v = 0; v < 3; ++v)
         for (int i = 0; i < 3; ++i) { tv[v][i] = W.verts[(size_t)(voff + fv[v]) * 3 + i]; tg[v][i] = W.vgrad[(size_t)(voff + fv[v]) * 3 + i]; }
     // value pass: the head as constants for the body-2 passes, and the normal-selection decision for all of them
-    int stable = -1;
+    int stable = stable_in;
     double cp1v[3], n1v[3], d1v, p1v[3];
     {
         BodyG<double> B1, B2;
@@ -97,6 +121,9 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         for (int i = 0; i < 3; ++i) { B1.pos[i] = P1[4 + i]; B2.pos[i] = P2[4 + i]; }
         make_shape(B1.shape, ty1, prm1, aux1);
         make_shape(B2.shape, ty2, prm2, aux2);
+#if DSS_ALL_SHAPES
+        B1.shape.lin = lin1; B2.shape.lin = lin2;
+#endif
         double nn[3], pp2[3], pen;
         contact_head(B1, tv, abc, cp1v, n1v, d1v, p1v);
         contact_tail(B1, B2, cp1v, n1v, d1v, p1v, 1e-3, nn, pp2, pen, &stable);
@@ -122,6 +149,9 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         }
         make_shape(B1.shape, ty1, pr1, aux1);
         make_shape(B2.shape, ty2, pr2, aux2);
+#if DSS_ALL_SHAPES
+        B1.shape.lin = lin1; B2.shape.lin = lin2;
+#endif
         D tri[3][3];
         for (int v = 0; v < 3; ++v)
             for (int i = 0; i < 3; ++i) {
@@ -153,6 +183,9 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         }
         make_shape(B1.shape, ty1, pr1, aux1);
         make_shape(B2.shape, ty2, pr2, aux2);
+#if DSS_ALL_SHAPES
+        B1.shape.lin = lin1; B2.shape.lin = lin2;
+#endif
         D cp1[3], n1[3], d1(d1v), p1[3], n[3], p2[3], pen;
         for (int i = 0; i < 3; ++i) { cp1[i] = D(cp1v[i]); n1[i] = D(n1v[i]); p1[i] = D(p1v[i]); }
         contact_tail(B1, B2, cp1, n1, d1, p1, 1e-3, n, p2, pen, &stable);
@@ -172,6 +205,9 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
             for (int i = 0; i < 3; ++i) { B1.pos[i] = D(P1[4 + i]); B2.pos[i] = D(P2[4 + i]); pr1[i] = D(prm1[i]); pr2[i] = D(prm2[i]); }
             make_shape(B1.shape, ty1, pr1, aux1);
             make_shape(B2.shape, ty2, pr2, aux2);
+#if DSS_ALL_SHAPES
+            B1.shape.lin = lin1; B2.shape.lin = lin2;
+#endif
             D tri[3][3];
             for (int v = 0; v < 3; ++v)
                 for (int i = 0; i < 3; ++i) {
@@ -191,6 +227,101 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     }
 #endif
 }
+
+#if DSS_ALL_SHAPES
+// ---- neural SDF bodies in the reverse sweep ------------------------------------------------------------------------------
+// The contact geometry of a neural body is differentiated through records of the network at the points it was queried at
+// (geom.h: igr_lin).  bwd_igr_prep_kernel lists those points for the sub-step every scene is about to undo -- body 1 at the
+// barycentric point of the contact's triangle, body 2 at the contact point in its frame -- igr_query_kernel evaluates the
+// list twice on the matrix cores (d/dxyz, d/dlatent), igr_records turns the answers into the records of one contact.
+__device__ inline bool in_cube3(const double *p, double s) { return fabs(p[0]) <= s && fabs(p[1]) <= s && fabs(p[2]) <= s; }
+
+__global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W, DssAdjoint A)
+{
+    const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
+    int k, act, init;
+    SlotView v;
+    bwd_select(W, A, sc, k, act, init, v);
+    if (!act && !init) return;
+    for (int c = lane; c < v.nc_n; c += 64) {
+        const int b1 = v.body_n[c], b2 = v.body_n[MX + c];
+        int idx[2] = {-1, -1};
+        for (int side = 0; side < 2; ++side) {
+            const int b = side ? b2 : b1;
+            if (W.shape_type[(size_t)sc * nb + b] != DSS_SHAPE_IGR) continue;
+            const double scale = W.shape_aux[(size_t)sc * nb + b];
+            double pt[3];
+            if (side == 0) {
+                const int mesh = W.mesh_id[(size_t)sc * nb + b1];
+                const int *fv = W.faces + (size_t)(W.mesh_foff[mesh] + v.face_n[c]) * 3;
+                pt[0] = pt[1] = pt[2] = 0.0;
+                for (int q = 0; q < 3; ++q) {
+                    const double *vp = W.verts + (size_t)(W.mesh_voff[mesh] + fv[q]) * 3, w = v.abc_n[(size_t)q * MX + c];
+                    for (int i = 0; i < 3; ++i) pt[i] = pt[i] + vp[i] * w;        // (the order of contact_head)
+                }
+                // contact_head forms tri[0] abc[0] + tri[1] abc[1] + tri[2] abc[2]: the same sum, left to right
+            } else {
+                const double *P1 = v.pose_n + 7 * b1, *P2 = v.pose_n + 7 * b2;
+                double rel[3];
+                for (int i = 0; i < 3; ++i) rel[i] = (v.geom_n[(size_t)(3 + i) * MX + c] + P1[4 + i]) - P2[4 + i];
+                quat_apply_inv(P2, rel, pt);
+            }
+            if (!in_cube3(pt, scale)) { idx[side] = -2; continue; }       // query_sdfs: phi = scale, grad = 0 out there
+            const int slot = atomicAdd(A.igr_bw_n, 1);
+            double u[3];
+            div3(pt, scale, u);
+            for (int i = 0; i < 3; ++i) A.igr_bw_pts[(size_t)slot * 3 + i] = u[i];
+            A.igr_bw_lat[slot] = sc * nb + b;
+            idx[side] = slot;
+        }
+        A.igr_bw_idx[((size_t)sc * 2 + 0) * MX + c] = idx[0];
+        A.igr_bw_idx[((size_t)sc * 2 + 1) * MX + c] = idx[1];
+    }
+}
+
+// records of contact c: lin[0 .. 2 IGR_LIN) body 1 (queries at the triangle point and after the Newton step), lin[2 IGR_LIN ..)
+// body 2; `stable` = which normal the forward pass picked, read off the taped normal
+__device__ void igr_records(const DssWorld &W, const DssAdjoint &A, int sc, const SlotView &v, int c, int i1, int i2, double *lin,
+                            int &stable)
+{
+    const int nb = W.nb, MX = W.maxc, b1 = v.body_n[c], b2 = v.body_n[MX + c];
+    const size_t cap = (size_t)W.B * 2 * MX;
+    const double *sdfX = A.igr_bw_sdf, *gX = A.igr_bw_grad, *gL = A.igr_bw_grad + cap * 3;
+    const double *P1 = v.pose_n + 7 * b1, *P2 = v.pose_n + 7 * b2;
+    for (int i = 0; i < 3 * IGR_LIN; ++i) lin[i] = 0.0;
+    auto fill = [&](double *r, int idx, double scale) {
+        if (idx < 0) { r[0] = scale; return; }      // outside the query cube: phi = scale, everything else zero
+        r[0] = sdfX[idx] * scale;
+        const double raw[3] = {gX[(size_t)idx * 3], gX[(size_t)idx * 3 + 1], gX[(size_t)idx * 3 + 2]};
+        for (int i = 0; i < 3; ++i) r[1 + i] = raw[i];                  // d (scale f(pt / scale)) / d pt
+        for (int j = 0; j < 2; ++j) r[4 + j] = gL[(size_t)idx * 3 + j] * scale;
+        normalize(raw, r + 6);
+    };
+    if (i1 != -1) fill(lin, i1, W.shape_aux[(size_t)sc * nb + b1]);
+    double n2[3];
+    if (i2 != -1) {
+        fill(lin + 2 * IGR_LIN, i2, W.shape_aux[(size_t)sc * nb + b2]);
+        for (int i = 0; i < 3; ++i) n2[i] = lin[2 * IGR_LIN + 6 + i];
+    } else {
+        Shape<double> s2;
+        make_shape(s2, W.shape_type[(size_t)sc * nb + b2], W.shape_prm + ((size_t)sc * nb + b2) * 3, W.shape_aux[(size_t)sc * nb + b2]);
+        double rel[3], cp2[3], d2;
+        for (int i = 0; i < 3; ++i) rel[i] = (v.geom_n[(size_t)(3 + i) * MX + c] + P1[4 + i]) - P2[4 + i];
+        quat_apply_inv(P2, rel, cp2);
+        query_sdf(s2, cp2, d2, n2, true);
+    }
+    const double nt[3] = {v.geom_n[c], v.geom_n[(size_t)MX + c], v.geom_n[(size_t)2 * MX + c]};
+    double n2w[3], dd = 0.0;
+    quat_apply(P2, n2, n2w);
+    for (int i = 0; i < 3; ++i) dd += (n2w[i] - nt[i]) * (n2w[i] - nt[i]);
+    stable = dd < 1e-18;
+    if (i1 != -1 && !stable) {       // the normal used is body 1's after the Newton step: n = -R1 n1'  ->  n1' = -R1^T n
+        double t[3];
+        quat_apply_inv(P1, nt, t);
+        for (int i = 0; i < 3; ++i) lin[IGR_LIN + 6 + i] = -t[i];
+    }
+}
+#endif
 
 // Ordered per-body sums of per-contact pieces:
 //   sums[b * NC + q] = sum over contacts c, in contact order, of [body1(c) = b] cs[row0[q]][c] + [body2(c) = b] cs[row1[q]][c].
@@ -224,23 +355,13 @@ __device__ inline void contact_sums(const int *body, int MX, int nc, int nb, con
 __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
 {
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
-    const int k = A.cur_slot[sc];
-    const int act = (k >= 0 && k >= A.lo_slot[sc] && k < W.nsub[sc] && k < W.max_sub);   // (a slot beyond the tape was never recorded)
-    // slot -1 = the contacts found at construction (World.__init__, world.py:96): only their geometry
-    // adjoint is left to push onto the initial pose and the shape parameters
-    const int init = (k == -1 && A.lo_slot[sc] <= -1 && W.nsub[sc] > 0);
+    int k, act, init;
+    SlotView v;
+    bwd_select(W, A, sc, k, act, init, v);
     if (lane == 0) A.bw_active[sc] = act;
     if (!act && !init) return;
-    SlotView v;
     double *a_pose = A.a_pose + (size_t)sc * nb * 7, *a_vel = A.a_vel + (size_t)sc * nb * 6;
     double *a_geom = A.a_geom + (size_t)sc * 10 * MX, *cs = A.cscr + (size_t)sc * DSS_CSCR_ROWS * MX;
-    if (init) {
-        const size_t r0 = (size_t)sc;   // tape slot 0
-        v.pose_n = W.tp_pose + r0 * nb * 7;
-        v.nc_n = W.tp_nc[r0]; v.body_n = W.tp_body + r0 * 2 * MX; v.face_n = W.tp_face + r0 * MX; v.abc_n = W.tp_abc + r0 * 3 * MX;
-    } else {
-        view_slot(W, sc, k, v);
-    }
 
     // (0) time-of-contact event (world.py:272-341): dt_h = H(dt_, theta).  Its adjoint is that of the redone
     //     move plus the carry from the next sub-step (whose dt_ = -last_dt + ...); H.backward (world.py:195-237)
@@ -347,7 +468,20 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         double gb[9], out[20];
         for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
         const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
-        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out, A.g_verts);
+        const double *l1 = nullptr, *l2 = nullptr;
+        int st = -1;
+#if DSS_ALL_SHAPES
+        double lin[3 * IGR_LIN];
+        if (A.igr_bw_idx) {
+            const int i1 = A.igr_bw_idx[((size_t)sc * 2 + 0) * MX + c], i2 = A.igr_bw_idx[((size_t)sc * 2 + 1) * MX + c];
+            if (i1 != -1 || i2 != -1) {
+                igr_records(W, A, sc, v, c, i1, i2, lin, st);
+                if (i1 != -1) l1 = lin;
+                if (i2 != -1) l2 = lin + 2 * IGR_LIN;
+            }
+        }
+#endif
+        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out, A.g_verts, l1, l2, st);
         for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
     }
     __syncthreads();
@@ -591,8 +725,18 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
 
 #if DSS_ALL_SHAPES
 namespace dss {
+int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
+                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream);
 void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stream)
 {
+    if (W.igr.W0 && A.igr_bw_idx) {
+        const int cap = W.B * 2 * W.maxc;
+        (void)hipMemsetAsync(A.igr_bw_n, 0, sizeof(int), stream);
+        hipLaunchKernelGGL(bwd_igr_prep_kernel, dim3(W.B), dim3(64), 0, stream, W, A);
+        launch_igr_list(W.igr, A.igr_bw_pts, A.igr_bw_lat, W.shape_prm, 3, A.igr_bw_n, cap, DSS_IGR_XYZ, A.igr_bw_sdf, A.igr_bw_grad, stream);
+        launch_igr_list(W.igr, A.igr_bw_pts, A.igr_bw_lat, W.shape_prm, 3, A.igr_bw_n, cap, DSS_IGR_LATENT, A.igr_bw_sdf + cap,
+                        A.igr_bw_grad + (size_t)cap * 3, stream);
+    }
     hipLaunchKernelGGL(bwd_pre_kernel, dim3(W.B), dim3(64), 0, stream, W, A);
 }
 }  // namespace dss

@@ -276,12 +276,12 @@ class BatchEngine:
     # -- backward ----------------------------------------------------------------------------------
     def _adjoint(self):
         if getattr(self, "adj", None) is None:
-            shp = abi.adjoint_shapes(self.B, self.nb, self.maxc, self.fd, int(self.arr["verts"].shape[0]))
+            shp = abi.adjoint_shapes(self.B, self.nb, self.maxc, self.fd, int(self.arr["verts"].shape[0]), igr=self.igr_items_cap > 0)
             kinds = dict(abi.ADJ_FIELDS)
             self.adj = {n: self.be.zeros(s, abi.NP_DTYPE[kinds[n]]) for n, s in shp.items()}
             A = abi.DssAdjoint()
             for n, _k in abi.ADJ_FIELDS:
-                setattr(A, n, self.be.ptr(self.adj[n]))
+                setattr(A, n, self.be.ptr(self.adj[n]) if n in self.adj else None)
             self.A = A
             L = self.be.lib
             L.dss_adjoint_sizeof.restype = ctypes.c_size_t

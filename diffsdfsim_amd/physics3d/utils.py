@@ -29,3 +29,10 @@ def get_tensor(x, base_tensor=None, **kw):
     if base_tensor is not None:
         return base_tensor.new_tensor(x, **kw)
     return torch.tensor(x, dtype=Defaults3D.DTYPE, **kw)
+
+
+def decode_igr(network):
+    """`decode_igr` (sdf_physics/physics3d/utils.py:330-350): IGR ImplicitNet -> ``sdf(pts, latent)`` evaluated on the device;
+    the result is what ``SDF3D(sdf_func=...)`` takes (diffsdfsim_amd/igr.py)."""
+    from ..igr import decode_igr as _decode
+    return _decode(network)

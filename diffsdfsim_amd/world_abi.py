@@ -112,6 +112,7 @@ ADJ_FIELDS = [
     ("g_mass", "pd"), ("g_inertia", "pd"), ("g_rest", "pd"), ("g_fric", "pd"), ("g_fext", "pd"), ("g_prm", "pd"), ("g_verts", "pd"),
     ("cur_slot", "pi"), ("lo_slot", "pi"), ("bw_active", "pi"),
     ("a_x", "pd"), ("dMblk", "pd"), ("dpvec", "pd"), ("dcop", "pd"), ("cscr", "pd"), ("bw_nc", "pi"),
+    ("igr_bw_n", "pi"), ("igr_bw_idx", "pi"), ("igr_bw_pts", "pd"), ("igr_bw_lat", "pi"), ("igr_bw_sdf", "pd"), ("igr_bw_grad", "pd"),
 ]
 
 
@@ -119,9 +120,13 @@ class DssAdjoint(ctypes.Structure):
     _fields_ = [(n, _P) for n, k in ADJ_FIELDS]
 
 
-def adjoint_shapes(B, nb, maxc, fd, NV=1):
+def adjoint_shapes(B, nb, maxc, fd, NV=1, igr=False):
     NFc = 3 * (1 + fd // 2) + 8
+    cap = B * 2 * maxc
+    extra = {"igr_bw_n": (1,), "igr_bw_idx": (B, 2, maxc), "igr_bw_pts": (cap, 3), "igr_bw_lat": (cap,), "igr_bw_sdf": (2, cap),
+             "igr_bw_grad": (2, cap, 3)} if igr else {}
     return {
+        **extra,
         "a_pose": (B, nb, 7), "a_vel": (B, nb, 6), "a_geom": (B, 10, maxc), "a_last_dt": (B,), "a_dt": (B,),
         "g_mass": (B, nb), "g_inertia": (B, nb, 9), "g_rest": (B, nb), "g_fric": (B, nb), "g_fext": (B, nb, 6),
         "g_prm": (B, nb, 3), "g_verts": (NV, 3), "cur_slot": (B,), "lo_slot": (B,), "bw_active": (B,),

@@ -275,6 +275,15 @@ typedef struct DssAdjoint {
     double *dMblk, *dpvec, *dcop;   /* LCP backward outputs, shapes of Mblk / pvec / cop */
     double *cscr;            /* [B][DSS_CSCR_ROWS][maxc] per-contact VJP pieces */
     int *bw_nc;              /* [B] */
+    /* neural SDF bodies: the network is re-evaluated at the contact points of the sub-step being undone (phi, d phi / d xyz
+       and d phi / d latent: what the reference's autograd keeps of SDF3D.query_sdfs, bodies.py:730-745 -- the value carries
+       the graph, the normal does not).  One compacted point list per dss_step_backward call; NULL without such bodies. */
+    int *igr_bw_n;           /* [1] points in the list */
+    int *igr_bw_idx;         /* [B][2][maxc] list slot of (contact, body 1 | body 2), -1 = that body is analytic */
+    double *igr_bw_pts;      /* [B 2 maxc][3] */
+    int *igr_bw_lat;         /* [B 2 maxc] */
+    double *igr_bw_sdf;      /* [2][B 2 maxc] phi from the xyz pass / the latent pass */
+    double *igr_bw_grad;     /* [2][B 2 maxc][3] d phi / d xyz, d phi / d latent */
 } DssAdjoint;
 
 size_t dss_adjoint_sizeof(void);

@@ -45,3 +45,20 @@ def engine_kwargs(g, **over):
               strict_no_pen=bool(g["strict_no_pen"]), maxc=64, max_cand=4096, max_pc=64)
     kw.update(over)
     return kw
+
+
+def torch_network(g):
+    """An ImplicitNet-shaped torch module (layers lin0..lin8, as the IGR repository's class the reference loads) holding the
+    golden's seeded weights: what a caller hands to decode_igr."""
+    import torch
+    Ws, bs = seeded_weights(g)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for l, (W, b) in enumerate(zip(Ws, bs)):
+                lin = torch.nn.Linear(W.shape[1], W.shape[0]).double()
+                with torch.no_grad():
+                    lin.weight.copy_(torch.tensor(W)); lin.bias.copy_(torch.tensor(b))
+                setattr(self, "lin%d" % l, lin)
+    return Net()

@@ -48,3 +48,54 @@ def test_neural_body_rollout_matches_reference(name):
     assert (pose == pose[:1]).all() and (vel == vel[:1]).all(), "replicated scenes diverged"
     for s in (0, 1):
         R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
+
+
+def build_world(g, latent):
+    """The golden's scene through the reference-shaped public surface (demos/demo_meshsdf.py:121-142 for rollout_igr_demo)."""
+    from diffsdfsim_amd.physics3d import Gravity3D, SDF3D, SDFBox, SDFCylinder, TotalConstraint3D, World3D
+    from diffsdfsim_amd.physics3d.utils import decode_igr
+    net = H.torch_network(g)
+    bodies, joints = [], []
+    for i, kind in enumerate(g["kind"]):
+        p0 = g["pose0"][i]
+        kw = dict(fric_coeff=float(g["fric"][i]), restitution=float(g["restitution"][i]))
+        if kind == 0:
+            b = SDFBox(p0.tolist(), g["shape_prm"][i].tolist(), custom_mesh=bool(g["custom_mesh"][i]), custom_inertia=bool(g["custom_mesh"][i]), **kw)
+        elif kind == 2:
+            b = SDFCylinder(p0.tolist(), float(g["shape_prm"][i][0]), float(g["shape_prm"][i][1]), **kw)
+        else:
+            b = SDF3D(pos=p0.tolist(), scale=float(g["igr_scale"]), sdf_func=decode_igr(net), params=[latent], vel=g["vel0"][i].tolist(), **kw)
+            b.add_force(Gravity3D())
+            obj = b
+        bodies.append(b)
+        if i in g["fixed"]:
+            joints.append(TotalConstraint3D(b))
+    nc = g["no_contact"]
+    for i in range(len(bodies)):
+        for j in range(i + 1, len(bodies)):
+            if nc[i, j]:
+                bodies[i].add_no_contact(bodies[j])
+    return World3D(bodies, joints), obj
+
+
+@pytest.mark.parametrize("name", ["rollout_igr_small", "rollout_igr_demo"])
+def test_latent_gradient_matches_reference_autograd(name):
+    """d loss / d latent of the demo's loss (demos/demo_meshsdf.py:89) through the whole rollout: through the network's value at
+    the contact points (the stepper's reverse sweep, matrix cores), through the level-set mesh (vertex adjoint -> MeshSDF
+    backward) and through the inertia integrated over that mesh.  The mesh here is the device's own (the network on the
+    matrix cores, not torch's CPU matmul), so poses agree to ~1e-9 rather than bit for bit."""
+    import torch
+    from diffsdfsim_amd.physics3d import run_world
+    g = R.load_rollout(name)
+    latent = torch.tensor(g["latent"], dtype=torch.float64, requires_grad=True)
+    w, obj = build_world(g, latent)
+    assert tuple(g["meshsize_%d" % int(g["igr_body"])]) == (len(obj.verts_np), len(obj.faces_np))
+    run_world(w, run_time=float(g["run_time"]), print_time=False)
+    assert len(w.trajectory) == len(g["traj_t"])
+    k = int(g["igr_body"])
+    assert np.abs(obj.p.detach().cpu().numpy() - g["traj_p"][-1][k]).max() < 1e-6
+    loss = (obj.pos - torch.tensor(g["target"], device=obj.pos.device)).norm() ** 2 + 0.05 * latent.norm() ** 2
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    loss.backward()
+    got, want = latent.grad.cpu().numpy(), g["grad_latent"]
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max(), (got, want)
