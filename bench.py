@@ -2,15 +2,20 @@
 """bench.py -- sim steps/s (fwd+bwd) of the batched differentiable SDF rigid-body stepper on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU; scenes are independent so every rank
-  steps its own shard of B scenes (weak scaling, no collective inside a step, one trivial gather of the
-  final poses at the end of the timed region).
-Workload = BASELINE.json configs[2]: 1024 scenes x 8 SDF bodies (floor + 7-box stack with friction).
-A "step" = one outer simulation step (World.step(fixed_dt=True)) of the whole batch, forward, plus its
-share of the backward sweep of sum |pos_T|^2; the timed region is K forward steps followed by the full
-reverse sweep through them.  Prints ONE JSON line on rank 0.
+  N > 1: one rank per GPU (torch.distributed.run, or this script as its own launcher); scenes are independent, so every
+  rank steps its own shard of B scenes (weak scaling, no collective inside a step, one trivial gather of the final poses and
+  per-scene gradients at the end of the timed region).
+Workloads (--config, numbered like BASELINE.json's list; 3 is the one the metric is quoted on and the default):
+  2  configs[1]  256 sphere-drop scenes, dt halving and time-of-contact events
+  3  configs[2]  1024 scenes x 8 SDF bodies (floor + 7-box stack with friction)
+  4  configs[3]  512 scenes of demos/demo_meshsdf.py: floor, pole, a NEURAL SDF body (MFMA MLP inside the narrow phase)
+  5  configs[4]  shape: 1024 contact-free single-body scenes per GPU (inertia fitting)
+A "step" = one outer simulation step (World.step(fixed_dt=True)) of the whole batch, forward, plus its share of the
+backward sweep of sum |pos_T|^2; the timed region is K forward steps followed by the full reverse sweep through them.
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,11 +26,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+FP64_PEAK_TFLOPS = 78.6      # vector and matrix fp64 alike: 256 CU x 128 flop/clk x 2.4 GHz
+IGR_MAC_PER_POINT = 115456   # 5*128 + 6*128*128 + 123*128 + 128: one network evaluation (igr_mlp.hip)
+
+DEFAULTS = {2: dict(batch=256, steps=200), 3: dict(batch=1024, steps=200), 4: dict(batch=512, steps=100), 5: dict(batch=1024, steps=200)}
+WORKLOAD = {2: "configs[1]: %d sphere-drop scenes (floor + SDF sphere, TOC on), %d steps fwd + reverse sweep",
+            3: "configs[2]: floor + 7-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep",
+            4: "configs[3]: demo_meshsdf scene (level-set floor, pole, neural-SDF body on the fp64 matrix cores), %d scenes per GPU, %d steps fwd + reverse sweep",
+            5: "configs[4] shape: %d contact-free single-body scenes per GPU (X/Y/Z constraints, torque), %d steps fwd + reverse sweep"}
 
 
 def lcp_algorithmic_bytes(nb, neq, fd, nc_per_scene):
-    """Operands in + results out of one contact-LCP launch (DESIGN.md §kernels), bytes."""
+    """Operands in + results out of one contact-LCP launch (DESIGN.md section 5), bytes."""
     ND, NR = fd // 2, fd + 2
     NF = 3 * (1 + ND) + 8
     per_scene_fixed = 8 * (36 * nb + 6 * nb + neq * 6 * nb + neq) + 8 * (6 * nb + neq) + 4
@@ -36,31 +49,56 @@ def lcp_algorithmic_bytes(nb, neq, fd, nc_per_scene):
 def detect_algorithmic_bytes(E):
     """Compulsory traffic of one contact-detection launch group (overlap + narrow phase + compaction), bytes:
     per active directed pair  culling boxes of mesh a (48 B/run) + centroid/radius of the faces in the runs that
-    pass (32 B/face) + triangle of every candidate (3 x 24 B + 12 B) + its Frank-Wolfe record written and read once
-    (15 x 8 B x 2) + contacts out (14 x 8 B), plus both bodies' state."""
+    pass (32 B/face) + triangle of every candidate (3 x 24 B + 12 B) + contacts out (14 x 8 B), plus both bodies' state."""
     st = E.get("pc_stats").astype(np.float64)
     cnt = E.get("pc_count").astype(np.float64)
     mesh_nf = E.get("mesh_nf")[E.get("mesh_id")].astype(np.float64)          # [B, nb]
     nb = E.nb
+    if nb < 2:
+        return 0.0
     a_of = np.repeat(np.arange(nb), nb - 1)                                   # mesh body of directed pair dp
     nch = np.ceil(mesh_nf[:, a_of] / 256.0)
     active = st[:, :, 0] > 0
-    per_pair = nch * 48 + st[:, :, 0] * 256 * 32 + st[:, :, 1] * (84 + 240) + cnt * 112 + 2 * 20 * 8
+    per_pair = nch * 48 + st[:, :, 0] * 256 * 32 + st[:, :, 1] * 84 + cnt * 112 + 2 * 20 * 8
     return float((per_pair * active).sum())
 
 
-def cpu_baseline(E, n_sample, threads):
-    """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of
-    batch.py / lcp.py) on the operands the GPU just solved, for a bounded sample of scenes."""
+def lib_hash():
+    from diffsdfsim_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def load_pmc(config):
+    """Counter totals per launch from rocprofv3 --pmc passes of this same command (tools/pmc.sh -> profiles/r2_pmc_config<N>.json),
+    valid only for the library build they were taken on (the file carries its hash)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_config%d.json" % config)))
+    except Exception:
+        return {}, "no PMC file for this config"
+    if d.get("lib_sha256") != lib_hash():
+        return {}, "PMC file is from another library build (%s): counters not reported" % d.get("lib_sha256")
+    return d.get("kernels", {}), None
+
+
+def pmc_sum(pmc, key, *frags):
+    tot, hit = 0.0, False
+    for k, v in pmc.items():
+        if any(f in k for f in frags) and key in v:
+            tot += v[key]; hit = True
+    return tot if hit else None
+
+
+def cpu_baseline_lcp(E, n_sample, threads):
+    """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of batch.py / lcp.py) on the
+    operands the GPU just solved, for a bounded sample of scenes; once on one thread, once with OpenMP over scenes."""
     from oracle import lcp_expand as X
     from oracle import lcp_oracle as O
     O.build()
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     P = dict(Mblk=E.get("Mblk"), pvec=E.get("pvec"), A=E.get("Je"), bvec=np.zeros((E.B, E.neq)), cop=E.get("cop"),
              cbody=E.get("cop_body"), nc=E.be.to_numpy(E.adj["bw_nc"]).copy(), nb=E.nb, neq=E.neq, maxc=E.maxc, fd=E.fd)
     ncs = P["nc"]
     pick = np.argsort(ncs)[len(ncs) // 2 - n_sample // 2: len(ncs) // 2 + (n_sample + 1) // 2]   # median-sized scenes
-    nineq_max = int(ncs[pick].max()) * (E.fd + 2)
+    nineq_max = max(1, int(ncs[pick].max()) * (E.fd + 2))
     ops = []
     for s in pick:   # pad to a common nineq with inert rows (h = 1, G = 0) so one batched call covers them
         Q, p, G, h, A, b, F = X.expand_dense(P, int(s))
@@ -69,11 +107,17 @@ def cpu_baseline(E, n_sample, threads):
         F = np.pad(F, ((0, k), (0, k)))
         ops.append((Q, p, G, h, A, b, F))
     Q, p, G, h, A, b, F = (np.stack(o) for o in zip(*ops))
-    t0 = time.time()
-    z, lam, sl, nu, it, st = O.forward(Q, p, G, h, A, b, F, max_iter=10, check_spd=True)
-    O.backward(Q, G, A, F, z, lam, sl, nu, np.ones_like(z))
-    dt = time.time() - t0
-    return dt / len(pick), len(pick), nineq_max
+
+    def run(nthreads, nscenes):
+        os.environ["OMP_NUM_THREADS"] = str(nthreads)
+        sl = slice(0, nscenes)
+        t0 = time.time()
+        z, lam, sl_, nu, it, st = O.forward(Q[sl], p[sl], G[sl], h[sl], A[sl], b[sl], F[sl], max_iter=10, check_spd=True)
+        O.backward(Q[sl], G[sl], A[sl], F[sl], z, lam, sl_, nu, np.ones_like(z))
+        return (time.time() - t0) / nscenes
+    one = run(1, min(2, len(pick)))            # seconds per scene, one thread
+    par = run(threads, len(pick))              # wall seconds per scene with `threads` scenes in flight
+    return one, par, len(pick), nineq_max
 
 
 def self_launch(n):
@@ -100,17 +144,43 @@ def self_launch(n):
     return rc
 
 
+def build_engine(args, rank, dev):
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.engine import BatchEngine, TorchBackend
+    B, K, Wm, cfg = args.batch, args.steps, args.warmup, args.config
+    be = TorchBackend(dev)
+    if cfg == 2:
+        spec = scenes.sphere_drop(B, seed=1000 + rank)
+        return BatchEngine(spec, maxc=64, max_cand=1024, max_pc=32, max_sub=4 * (K + Wm) + 64, backend=be)
+    if cfg == 3:
+        spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=args.push)
+        # strict_no_pen=False as in the reference's own long-running experiments (optim_sysid.py:104-131): a scene
+        # whose penetration cannot be resolved by halving dt proceeds once dt < dt/2^10 (world.py:345-347) instead of
+        # retrying forever, which with strict=True stalls the reference as well.
+        return BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16, strict_no_pen=False, backend=be)
+    if cfg == 4:
+        spec = scenes.igr_pole(B, seed=1000 + rank)
+        return BatchEngine(spec, maxc=256, max_cand=8192, max_pc=128, max_sub=3 * (K + Wm) + 64, backend=be)
+    spec = scenes.inertia_spin(B, seed=1000 + rank)
+    return BatchEngine(spec, maxc=8, max_cand=64, max_pc=8, max_sub=(K + Wm) + 16, backend=be)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(DEFAULTS))
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="scenes per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU")
     ap.add_argument("--nbox", type=int, default=7)
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULTS[args.config]["steps"]
+    if args.batch is None:
+        args.batch = DEFAULTS[args.config]["batch"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- N children, one rank per GPU, started BEFORE anything in
@@ -144,17 +214,15 @@ def main():
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if backend == "gloo" else dev      # where collective buffers live
 
-    from diffsdfsim_amd import _lib, scenes
-    from diffsdfsim_amd.engine import BatchEngine, TorchBackend
+    from diffsdfsim_amd import _lib
+    from diffsdfsim_amd import world_abi as abi
     _lib.lib()   # fail loudly if the HIP library is missing
 
-    B, K, Wm = args.batch, args.steps, args.warmup
-    spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=args.push)
-    # strict_no_pen=False as in the reference's own long-running experiments (optim_sysid.py:104-131): a scene
-    # whose penetration cannot be resolved by halving dt proceeds once dt < dt/2^10 (world.py:345-347) instead of
-    # retrying forever, which with strict=True stalls the reference as well.
-    E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16,
-                    strict_no_pen=False, backend=TorchBackend(dev))
+    B, K, Wm, cfg = args.batch, args.steps, args.warmup, args.config
+    t_build = time.time()
+    E = build_engine(args, rank, dev)
+    t_build = time.time() - t_build
+    neural = E.igr_items_cap > 0
 
     def loss_adjoint():
         adj = E._adjoint()
@@ -172,7 +240,7 @@ def main():
     E.backward_sweep(att)
     torch.cuda.synchronize()
 
-    # event pairs around every LCP launch of the timed region
+    # event pairs around every LCP launch and every detection launch group of the timed region
     ev = []
 
     def fresh_pair():
@@ -180,12 +248,21 @@ def main():
         a.record(); b.record()
         return a, b
 
-    pool = [fresh_pair() for _ in range(8 * K + 128)]
+    est = {2: 12, 3: 2, 4: 3, 5: 2}[cfg]
+    pool = [fresh_pair() for _ in range(2 * est * K + 256)]
+    # neural narrow phase: event pairs around the network evaluations of one attempt in IGR_EV_EVERY (the matrix-core kernel)
+    IGR_EV_EVERY = 4
+    nev = 4 * (abi.IGR_ROUNDS + 1)
+    igr_events = [torch.cuda.Event(enable_timing=True) for _ in range(nev)] if neural else []
+    for e in igr_events:
+        e.record()
+    import ctypes
+    igr_ev_arr = (ctypes.c_void_p * nev)(*[e.cuda_event for e in igr_events]) if neural else None
+    igr_ms, igr_pts = [], []           # per sampled launch: duration, (value points, gradient points)
+    qn_total = torch.zeros(2 * (abi.IGR_ROUNDS + 2), dtype=torch.int64, device=dev) if neural else None
     torch.cuda.synchronize()
     lo = E.arr["nsub"].clone()
-    nc_hist = []
 
-    import ctypes
     L = E.be.lib
 
     def timed_step():
@@ -193,16 +270,29 @@ def main():
         E._check(L.dss_step_begin(ctypes.byref(E.W), E.be.stream()), "dss_step_begin")
         n, k = E.B, 0
         while n > 0:
+            if 2 * len(ev) + 1 >= len(pool):
+                pool.extend(fresh_pair() for _ in range(256))
             a, b = pool[2 * len(ev)]
             c, d = pool[2 * len(ev) + 1]
             E.W.ev_lcp_start, E.W.ev_lcp_stop = a.cuda_event, b.cuda_event
             E.W.ev_np_start, E.W.ev_np_stop = c.cuda_event, d.cuda_event
+            sample = neural and len(ev) % IGR_EV_EVERY == 0
+            E.W.igr_ev = ctypes.cast(igr_ev_arr, ctypes.c_void_p) if sample else None
             E._check(L.dss_step_attempt(ctypes.byref(E.W), ctypes.c_void_p(E.be.ptr(E.lcp_ws)),
                                         ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream()), "dss_step_attempt")
             ev.append((a, b, c, d))
-            n = E.be.read_int(E.arr["n_active"])
+            if neural:
+                qn_total.add_(E.arr["igr_qn"])
+            n = E.be.read_int(E.arr["n_active"])        # (the one host read of an attempt; the stream is idle afterwards)
             if n & (1 << 30):
                 E._raise_overflow()
+            if sample:
+                qn = E.get("igr_qn")
+                for r in range(1, abi.IGR_ROUNDS + 1):
+                    for l in range(2):
+                        if qn[2 * r + l] > 0:
+                            igr_ms.append(igr_events[4 * r + 2 * l].elapsed_time(igr_events[4 * r + 2 * l + 1]))
+                            igr_pts.append((int(qn[2 * r + l]), l))
             k += 1
         return k
 
@@ -214,6 +304,8 @@ def main():
     for _ in range(K):
         att += timed_step()
     E.W.ev_lcp_start, E.W.ev_lcp_stop, E.W.ev_np_start, E.W.ev_np_stop = None, None, None, None
+    E.W.igr_ev = None
+    t_fwd = time.perf_counter()
     loss_adjoint()
     E.adj["lo_slot"].copy_(lo)
     E.backward_sweep(att)
@@ -228,6 +320,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    fwd_s = t_fwd - t0
     if dist is not None:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,62 +332,102 @@ def main():
     det_ms = np.array([c.elapsed_time(d) for a, b, c, d in ev])
     nc = E.get("nc")
     overflow = int(E.get("overflow").max())
-
-    # HBM traffic per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE collected in
-    # separate passes, profiles/r1_pmc_traffic.json); KB -> bytes, no access-width correction applied (MI355X guide:
-    # FETCH_SIZE under-reports wide streaming reads by 2x; these kernels read 8-byte strided fields, uncalibrated).
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-    except Exception:
-        pass
+    pmc, pmc_note = load_pmc(cfg)
 
     def traffic(*frags):
-        tot = 0.0
-        for k, v in pmc.items():
-            if any(f in k for f in frags):
-                tot += (v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024.0
-        return tot or None
+        f, w = pmc_sum(pmc, "FETCH_SIZE_KB_avg", *frags), pmc_sum(pmc, "WRITE_SIZE_KB_avg", *frags)
+        return None if f is None or w is None else (f + w) * 1024.0
 
-    def roof(kernel, ms, algo, note, tr):
-        ach = algo / (ms.mean() * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_ms": float(ms.mean()), "launches": len(ms),
-                "algorithmic_bytes_per_launch": algo, "note": note}
+    def fp64_flops(*frags):
+        """fp64 flops per launch from the SQ instruction counters (wave instructions x 64 lanes; FMA = 2)."""
+        a, m, f = (pmc_sum(pmc, "SQ_INSTS_VALU_%s_F64_avg" % k, *frags) for k in ("ADD", "MUL", "FMA"))
+        return None if a is None or m is None or f is None else 64.0 * (a + m + 2.0 * f)
 
-    r_lcp = roof("lcp_contact_forward_reg_kernel<4>", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
-                 "one wavefront per scene and SIMD, KKT and IPM state in registers: bound by the serial fp64 issue latency "
-                 "of one wavefront, not by HBM; traffic above the algorithmic bytes is register spill around the "
-                 "factorisation (DESIGN.md section 5)",
-                 traffic("lcp_contact_forward"))
-    r_det = roof("narrowphase_kernel (+overlap_kernel, compact_contacts_kernel)", det_ms, detect_algorithmic_bytes(E),
-                 "Frank-Wolfe / SDF evaluation: fp64 VALU bound (61 % VALU-busy, SQ_ACTIVE_INST_VALU; IEEE div/sqrt "
-                 "sequences), not HBM (DESIGN.md section 5)",
-                 traffic("narrowphase_kernel", "overlap_kernel", "compact_contacts"))
-    dominant, other = (r_det, r_lcp) if det_ms.mean() >= lcp_ms.mean() else (r_lcp, r_det)
+    def roof_valu(kernel, ms, algo_bytes, note, frags):
+        """A kernel that is fp64-VALU / issue bound, not HBM bound: fp64 flops (PMC, if taken on this build) over the measured
+        launch time against the 78.6 TFLOP/s vector peak; the HBM view (algorithmic bytes / time) rides along."""
+        fl = fp64_flops(*frags)
+        t = ms.mean() * 1e-3
+        hbm = algo_bytes / t / 1e9
+        r = {"bound": "fp64_valu", "kernel": kernel, "avg_launch_ms": float(ms.mean()), "launches": len(ms),
+             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": traffic(*frags),
+             "algorithmic_bytes_per_launch": algo_bytes, "hbm_view": {"achieved_GBps": hbm, "frac_of_8TBps": hbm / HBM_PEAK_GBS},
+             "note": note}
+        if fl is None:
+            r.update(achieved=None, frac=None, flops_per_launch=None, flops_note=pmc_note or "no fp64 instruction counters in the PMC file")
+        else:
+            r.update(achieved=fl / t / 1e12, frac=fl / t / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=fl)
+            vb = pmc_sum(pmc, "valu_busy_frac", *frags)
+            if vb is not None:
+                r["valu_busy_frac"] = vb
+        return r
+
+    r_lcp = roof_valu("lcp_contact_forward_reg_kernel", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
+                      "one scene per wavefront, reduced KKT and interior-point state in registers: bound by fp64 issue of a "
+                      "serial chain, not by HBM (operands are 35 KB per scene)", ("lcp_contact_forward",))
+    r_det = roof_valu("narrowphase_kernel (+overlap_kernel, compact_contacts_kernel)", det_ms, detect_algorithmic_bytes(E),
+                      "Frank-Wolfe / SDF evaluation: fp64 VALU bound (IEEE div/sqrt sequences), not HBM",
+                      ("narrowphase_kernel", "overlap_kernel", "compact_contacts"))
+    extra = {}
+    if neural and igr_ms:
+        ms = np.array(igr_ms)
+        flops = np.array([2.0 * IGR_MAC_PER_POINT * n * (4 if l == 1 else 1) for n, l in igr_pts])
+        tot = qn_total.cpu().numpy()
+        nv, ng = int(tot[2::2].sum()), int(tot[3::2].sum())
+        ach = flops.sum() / (ms.sum() * 1e-3) / 1e12
+        big = flops >= np.percentile(flops, 90)
+        r_igr = {"bound": "mfma", "kernel": "igr_query_kernel (fp64 v_mfma_f64_16x16x4)", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic("igr_query_kernel"),
+                 "avg_launch_ms": float(ms.mean()), "launches_sampled": len(ms),
+                 "algorithmic_flops_per_launch": float(flops.mean()),
+                 "largest_decile_launches": {"TFLOPs": float(flops[big].sum() / (ms[big].sum() * 1e-3) / 1e12), "avg_points": float(np.mean([n for (n, l), b in zip(igr_pts, big) if b]))},
+                 "points_evaluated": {"value_only": nv, "with_gradient": ng, "per_step": (nv + ng) / K},
+                 "mfma_busy_frac": pmc_sum(pmc, "mfma_busy_frac", "igr_query_kernel"),
+                 "note": "network evaluations of the neural narrow phase, one launch per query round and list; flops = 2 x 115456 MAC per "
+                         "point (x4 with the three xyz tangents); events around one attempt in %d" % IGR_EV_EVERY}
+        dominant, other = r_igr, r_det
+        extra["roofline_third_kernel"] = r_lcp
+    else:
+        dominant, other = (r_det, r_lcp) if det_ms.mean() >= lcp_ms.mean() else (r_lcp, r_det)
     res = {
-        "metric": "sim steps/sec (fwd+bwd), 1024 batched 3D scenes x 8 SDF bodies",
+        "metric": "sim steps/sec (fwd+bwd), 1024 batched 3D scenes x 8 SDF bodies" if cfg == 3 else
+                  "sim steps/sec (fwd+bwd), BASELINE configs[%d]" % (cfg - 1),
         "value": world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[2]: floor + %d-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep"
-                               % (args.nbox, B, K),
+        "config": {"workload": WORKLOAD[cfg] % (B, K),
                    "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
                    "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()),
                    "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
+                   "forward_s": fwd_s, "backward_s": dt - fwd_s, "world_build_s": t_build,
+                   "lib_sha256": lib_hash(),
                    "parallelism": "scene-sharded x%d, no collective in step; one all_gather (%s) of final poses + per-scene "
                                   "gradients; %d physical device(s)" % (world, backend or "none", torch.cuda.device_count())},
         "roofline": dominant, "roofline_second_kernel": other,
     }
+    res.update(extra)
+    if pmc_note:
+        res["config"]["pmc_note"] = pmc_note
     if not args.no_cpu:
         threads = min(os.cpu_count() or 1, args.cpu_sample)
-        per_scene, ns, nineq = cpu_baseline(E, args.cpu_sample, threads)
-        # per_scene is wall/scene with `threads` scenes in flight; a 1024-scene step needs 1024 * per_scene seconds
-        res["cpu_baseline"] = {"value": 1.0 / (B * per_scene), "unit": "steps/s", "cores": threads, "kind": "port",
-                               "sample": "dense PDIPM LCP fwd+bwd only (oracle/lcp_oracle.c, the reference's algorithm) on the "
-                                         "operands of %d median scenes of this batch (nineq=%d), OpenMP over scenes, scaled to %d "
-                                         "scenes; contact detection not included, so this over-states the CPU" % (ns, nineq, B)}
+        if int(E.be.to_numpy(E.adj["bw_nc"]).max()) > 0:
+            one, par, ns, nineq = cpu_baseline_lcp(E, args.cpu_sample, threads)
+            gpu_lcp_share = float(lcp_ms.mean())    # + the backward LCP kernel, not timed separately (about 8 % of the forward's)
+            res["cpu_baseline"] = {
+                "value": 1.0 / (B * par), "unit": "steps/s (LCP share only)", "cores": threads, "kind": "port",
+                "covers": "LCP forward+backward ONLY -- contact detection (half of the GPU step) has no CPU leg, so this is not a "
+                          "whole-step baseline and the ratio to `value` must not be quoted; compare with gpu_lcp_share_ms_per_step",
+                "lcp_s_per_scene_1_thread": one, "lcp_s_per_scene_wall_at_%d_threads" % threads: par,
+                "gpu_lcp_share_ms_per_step": gpu_lcp_share,
+                "reference_lapack_lcp_s_per_scene": {"value": 0.078, "where": "the reference's own torch/LAPACK LCPFunction fwd+bwd at nineq=560 "
+                                                     "on the 8-vCPU build container (SURVEY.md section 6); the plain-C port here is several "
+                                                     "times slower than that"},
+                "sample": "dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, the reference's algorithm, unblocked LU) on the operands of %d "
+                          "median scenes of this batch (nineq=%d), scaled to %d scenes" % (ns, nineq, B)}
+        else:
+            res["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": threads, "kind": "port",
+                                   "sample": "no contacts in this workload at the end of the run: the dense-LCP port has nothing to time"}
     print(json.dumps(res))
 
 

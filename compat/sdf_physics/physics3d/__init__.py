@@ -1,0 +1,1 @@
+"""Module-name alias package (compat/README.md)."""

@@ -1,0 +1,5 @@
+"""`sdf_physics.physics3d.constraints` of the reference, served by the MI355X build (see compat/README.md)."""
+from diffsdfsim_amd.physics3d.constraints import *  # noqa: F401,F403
+from diffsdfsim_amd.physics3d import constraints as _m
+
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

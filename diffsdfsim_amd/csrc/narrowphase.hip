@@ -545,6 +545,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     }
     if (G::any(bad)) {
         if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
+        // attempts that will be accepted all the same (decide_kernel: strict_no_penetration=False, dt < dt / 2^10) keep this
+        // direction's contacts as they are
+        if (!W.strict_no_pen && W.dt_try[sc] < W.dt / 1024.0) { G::sync(); emit_unfiltered<G>(W, sc, dp, ncon, over, kface, cb, MC); }
         return 0;
     }
 
@@ -609,6 +612,7 @@ __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *n
     constexpr int MAXSLOT = 64 * 63;
     __shared__ int s_off[MAXSLOT + 1];
     __shared__ short s_a[MAXSLOT], s_b[MAXSLOT];
+    __shared__ unsigned char s_neg[MAXSLOT];
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, np = npairs_of(nb), MP = W.max_pc, MX = W.maxc;
     if (!W.active[sc]) return;
     int run = 0;
@@ -622,6 +626,12 @@ __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *n
             a = (slot & 1) ? j : i; b = (slot & 1) ? i : j;
             cnt = W.pc_count[(size_t)sc * np + a * (nb - 1) + (b < a ? b : b - 1)];
         }
+        // a negative count = the contacts of a direction that met a penetration in an attempt that goes through anyway
+        // (emit_unfiltered): the reference does not search the reverse direction then (contacts.py:237-240)
+        const int fwd = __shfl_up(cnt, 1, 64);       // (slots come in pairs i->j, j->i; 64 is even)
+        if ((slot & 1) && fwd < 0) cnt = 0;
+        if (slot < np) s_neg[slot] = cnt < 0;
+        if (cnt < 0) cnt = -cnt;
         int incl = cnt;   // inclusive scan over the wavefront
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
         if (slot < np) { s_off[slot] = run + incl - cnt; s_a[slot] = (short)a; s_b[slot] = (short)b; }
@@ -637,7 +647,9 @@ __global__ void __launch_bounds__(64) compact_contacts_kernel(DssWorld W, int *n
         const size_t dp = (size_t)sc * np + a * (nb - 1) + (b < a ? b : b - 1);
         const int *pf = W.pc_face + dp * MP;
         const double *pabc = W.pc_abc + dp * 3 * MP, *pg = W.pc_geom + dp * 10 * MP;
-        const int face = pf[k];   // loads first, stores after (no load has to wait behind a possibly aliasing store)
+        // loads first, stores after (no load has to wait behind a possibly aliasing store).  A contact of a penetrating
+        // direction was computed under no_grad in the reference: its face id is stored as -1 - face (no geometry adjoint)
+        const int face = s_neg[lo] ? -1 - pf[k] : pf[k];
         double abc[3], geo[10];
         for (int f = 0; f < 3; ++f) abc[f] = pabc[(size_t)f * MP + k];
         for (int f = 0; f < 10; ++f) geo[f] = pg[(size_t)f * MP + k];

@@ -638,9 +638,11 @@ int launch_igr_rounds(const DssWorld &W, hipStream_t stream)
             const int set = r & 1;
             for (int l = 0; l < 2; ++l) {
                 const size_t o = (size_t)(2 * set + l) * W.igr_qcap;
+                if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l], stream);
                 const int rc = launch_igr_list(W.igr, W.igr_qpts + o * 3, W.igr_qlat + o, W.shape_prm, 3, W.igr_qn + 2 * r + l, W.igr_qcap,
                                                l == L_VALUE ? DSS_IGR_VALUE : DSS_IGR_XYZ, W.igr_qsdf + o,
                                                W.igr_qgrad + (size_t)set * W.igr_qcap * 3, stream);
+                if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l + 1], stream);
                 if (rc) return rc;
             }
         }

@@ -528,6 +528,31 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
     }
     G::sync();
 }
+// The escape of world.py:345-347 (strict_no_penetration=False and dt already below dt / 2^10): the step goes through with the
+// contacts as _search_contacts left them when it met a penetration (contacts.py:249-272) -- every contact of this direction,
+// unthinned, computed under no_grad.  They are written with NEGATIVE count: the gather stage drops the reverse direction of
+// the pair (which the reference then does not search) and marks the contacts as gradient-free.
+template <class G>
+__device__ __noinline__ void emit_unfiltered(const DssWorld &W, int sc, int dp, int ncon, int over, const int *kface, const double *cb, int MC)
+{
+    const int np = npairs_of(W.nb), tid = G::tid(), MP = W.max_pc;
+    int *pf = W.pc_face + ((size_t)sc * np + dp) * MP;
+    double *pabc = W.pc_abc + ((size_t)sc * np + dp) * 3 * MP, *pg = W.pc_geom + ((size_t)sc * np + dp) * 10 * MP;
+    int nout = ncon;
+    if (nout > MP) { over |= 4; nout = MP; }
+    for (int k = tid; k < nout; k += G::BT) {
+        pf[k] = kface[k];
+        for (int i = 0; i < 3; ++i) {
+            pabc[(size_t)i * MP + k] = cb[(size_t)(15 + i) * MC + k];
+            pg[(size_t)i * MP + k] = cb[(size_t)(18 + i) * MC + k];
+            pg[(size_t)(3 + i) * MP + k] = cb[(size_t)(21 + i) * MC + k];
+            pg[(size_t)(6 + i) * MP + k] = cb[(size_t)i * MC + k];
+        }
+        pg[(size_t)9 * MP + k] = cb[(size_t)24 * MC + k];
+    }
+    if (tid == 0) { W.pc_count[(size_t)sc * np + dp] = -nout; if (over) atomicOr(W.overflow + sc, over); }
+}
+
 // ---- stages 5 and 6 of a work item: thin the contacts (greedy normal clusters, hull of each; contacts.py:97-158) and
 // write the kept ones, in ascending face order, to the pair's output slots.  On entry the candidate scratch holds, for
 // contacts k < ncon: kface[k], barycentrics (fields 15-17), normal (18-20), p1 (21-23), p2 (0-2), penetration (24).

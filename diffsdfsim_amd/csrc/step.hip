@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
             toc |= !(((s_pairs[ab >> 5] >> (ab & 31)) | (s_pairs[ba >> 5] >> (ba & 31))) & 1u);
         }
         toc = __ballot(toc) != 0ull;
+        // the escape of world.py:345-347 leaves the loop before toc_contacts / last_dt are touched
+        const bool escaped = W.invalid[sc] != 0;
+        if (escaped) toc = W.toc[sc];
         // tape record of the accepted sub-step
         const int slot = W.nsub[sc];
         // the tape is full: the sub-step cannot be recorded, a reverse sweep over it would read past the tape.  A capacity
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
             }
             if (lane == 0) {
                 W.tp_dt[rec] = W.dt_use[sc]; W.tp_nc[rec] = nc_old;
-                W.tp_flags[rec] = ((W.toc_diff && toc) ? 1 : 0) | ((W.toc_diff && W.toc[sc]) ? 2 : 0);
+                W.tp_flags[rec] = ((W.toc_diff && toc && !escaped) ? 1 : 0) | ((W.toc_diff && W.toc[sc]) ? 2 : 0);
             }
         }
         __syncthreads();
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
         if (lane == 0) {
             W.nc[sc] = nc_new;
             W.toc[sc] = toc;
-            if (W.toc_diff && toc) W.last_dt[sc] = W.dt_use[sc];   // world.py:341
+            if (W.toc_diff && toc && !escaped) W.last_dt[sc] = W.dt_use[sc];   // world.py:341
             W.nsub[sc] = slot + 1;
             const double t = W.t[sc] + dt_try;                     // self.t += dt   (world.py:379)
             W.t[sc] = t;

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W, DssAdjoint
     for (int c = lane; c < v.nc_n; c += 64) {
         const int b1 = v.body_n[c], b2 = v.body_n[MX + c];
         int idx[2] = {-1, -1};
-        for (int side = 0; side < 2; ++side) {
+        for (int side = 0; side < 2 && v.face_n[c] >= 0; ++side) {
             const int b = side ? b2 : b1;
             if (W.shape_type[(size_t)sc * nb + b] != DSS_SHAPE_IGR) continue;
             const double scale = W.shape_aux[(size_t)sc * nb + b];
@@ -468,6 +468,10 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
         double gb[9], out[20];
         for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
         const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
+        if (v.face_n[c] < 0) {      // a contact kept from a penetrating direction (world.py:345-347): computed under no_grad
+            for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = 0.0;
+            continue;
+        }
         const double *l1 = nullptr, *l2 = nullptr;
         int st = -1;
 #if DSS_ALL_SHAPES

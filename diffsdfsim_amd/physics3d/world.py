@@ -235,7 +235,8 @@ class World3D(BatchWorld3D):
         had = bool(BatchWorld3D.step(self, fixed_dt)[0])
         self._t = float(self.engine.get("t")[0])
         self._sync_bodies()
-        self.trajectory.append((self._t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), None, None))
+        # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-377 appends them; contacts by value
+        self.trajectory.append((self._t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), self.contacts, None))
         return had
 
     def get_v(self):

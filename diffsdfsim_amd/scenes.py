@@ -111,3 +111,93 @@ def sphere_drop(B, seed=0, floor_dims=(20.0, 1.0, 20.0), mu=0.25, rest=0.5, g=10
         spec["restitution"][s, 1] = rest
         spec["fext"][s, 1, 4] = -g
     return spec
+
+
+def igr_pole(B, seed=0, packed=None, radius_init=0.5, latent_sigma=0.1, y0=6.0, res=128, mu=0.15, g=10.0, floor_dims=(50.0, 1.0, 50.0)):
+    """config 4 (BASELINE configs[3]): ``demos/demo_meshsdf.make_world`` (demo_meshsdf.py:121-142) for a batch -- level-set floor
+    50 x 1 x 50, pinned cylinder pole (r 0.2, h 2, upright at x = 0.35, no contact with the floor), one neural-SDF body of scale
+    2 per scene dropped from y = 6 with its own latent code ~ N(0, sigma^2).  The trained IGR weights are not available
+    offline: ``packed`` defaults to seeded geometric-init weights of the bob_spot_setup shape (synthetic, like all data here).
+    Needs the HIP device: the level-set meshes and their inertias are built by the device operators."""
+    import torch
+    from . import igr, mass_properties, meshsdf
+    r = np.random.default_rng(seed)
+    if packed is None:
+        packed = igr.pack_weights(*geometric_init_weights(seed, radius_init))
+    nb = 3
+    spec, cache = _base(B, nb), {}
+    spec["Je"] = np.zeros((B, 12, 6 * nb))
+    spec["Je"][:, :6, :6] = np.eye(6)            # TotalConstraint3D(floor), TotalConstraint3D(pole)
+    spec["Je"][:, 6:, 6:12] = np.eye(6)
+    nocon = np.zeros((nb, nb), np.uint8); nocon[0, 1] = nocon[1, 0] = 1
+    spec["no_contact"] = nocon
+    spec["shape_aux"] = np.zeros((B, nb))
+    spec["igr_net"] = packed
+    fd = np.asarray(floor_dims, np.float64)
+
+    def level_set(kind, prm, scale):
+        v, f = meshsdf.primitive_mesh(kind, np.concatenate([prm, [0.0]]) / scale, res=res)
+        v = (v * scale).cpu().numpy(); f = f.cpu().numpy()
+        return v, f, np.asarray(mass_properties.mesh_inertia(v, f, 1.0).cpu())
+    fs = fd.max() * 1.5 / 2
+    fv, ff, fJ = level_set(abi.SHAPE_BOX, fd, fs)
+    prm_p = np.array([0.2, 2.0, 0.0]); ps = max(prm_p[0], prm_p[1] / 2) * 1.5
+    pv, pf, pJ = level_set(abi.SHAPE_CYLINDER, prm_p, ps)
+    spec["meshes"] += [(fv, ff), (pv, pf)]
+    spec["mesh_vgrad"] += [np.zeros_like(fv), np.zeros_like(pv)]
+    spec["pose"][:, 0, 4:] = (0.0, -fd[1] / 2, 0.0)
+    spec["shape_prm"][:, 0] = fd; spec["inertia"][:, 0] = fJ; spec["fric"][:, 0] = mu; spec["restitution"][:, 0] = 0.0
+    spec["shape_type"][:, 1] = abi.SHAPE_CYLINDER
+    spec["pose"][:, 1, :4] = _quat_from_euler(math.pi / 2, 0.0, 0.0)
+    spec["pose"][:, 1, 4:] = (0.35, 1.0, 0.0)
+    spec["shape_prm"][:, 1] = prm_p; spec["inertia"][:, 1] = pJ; spec["fric"][:, 1] = mu
+    spec["restitution"][:, 1] = 0.5              # Defaults3D.RESTITUTION (the demo does not set it for the pole)
+    spec["mesh_id"][:, 1] = 1
+    spec["shape_type"][:, 2] = abi.SHAPE_IGR
+    spec["shape_aux"][:, 2] = 2.0
+    for s in range(B):
+        lat = latent_sigma * r.standard_normal(2)
+        v, f = meshsdf.igr_mesh(torch.tensor(lat, dtype=torch.float64), packed, res=res)
+        v = (v * 2.0).cpu().numpy(); f = f.cpu().numpy()
+        spec["meshes"].append((v, f)); spec["mesh_vgrad"].append(np.zeros_like(v))
+        spec["mesh_id"][s, 2] = 2 + s
+        spec["shape_prm"][s, 2, :2] = lat
+        spec["inertia"][s, 2] = np.asarray(mass_properties.mesh_inertia(v, f, 1.0).cpu())
+        spec["pose"][s, 2, 4:] = (0.0, y0, 0.0)
+        spec["fric"][s, 2] = mu
+        spec["fext"][s, 2, 4] = -g
+    return spec
+
+
+def geometric_init_weights(seed=0, radius_init=0.5):
+    """IGR's geometric initialisation (Atzmon & Lipman 2020; the network constructor of the external IGR repository) for the
+    bob_spot_setup shape (IGR_data/train_configs/bob_spot_setup.conf:38-45): every hidden layer N(0, 2/out), the last layer
+    mean sqrt(pi)/sqrt(128) and bias -radius, seeded numpy.  Synthetic stand-in for the trained weights (README.md:41-42:
+    a download, unavailable offline)."""
+    r = np.random.default_rng(seed)
+    dims = [5] + [128] * 8 + [1]
+    Ws, bs = [], []
+    for l in range(9):
+        out = dims[l + 1] - 5 if l + 1 == 4 else dims[l + 1]
+        if l == 8:
+            Ws.append(r.normal(np.sqrt(np.pi) / np.sqrt(dims[l]), 1e-5, (out, dims[l]))); bs.append(np.full(out, -radius_init))
+        else:
+            Ws.append(r.normal(0.0, np.sqrt(2) / np.sqrt(out), (out, dims[l]))); bs.append(np.zeros(out))
+    return Ws, bs
+
+
+def inertia_spin(B, seed=0):
+    """config 5 shape (BASELINE configs[4], experiments/inertia_fitting/optim_shapespace.py:71-92): one body per scene, its
+    translation locked by X/Y/Z constraints, a constant torque about a random axis, no contacts (the engine's linear-solve
+    branch, engines.py:40-54).  The body's inertia is the fitted quantity; an icosphere stands in for the shape mesh (the
+    stepping cost does not depend on it: nothing collides)."""
+    r = np.random.default_rng(seed)
+    v, f = meshes.icosphere(3)
+    dirs = r.standard_normal((B, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    I0 = np.stack([np.diag(0.1 + 0.2 * r.random(3)) for _ in range(B)])[:, None]
+    one = lambda a: np.tile(np.asarray(a, np.float64), (B, 1, 1))
+    return dict(pose=one([1.0, 0, 0, 0, 0, 0, 0]), vel=one(np.zeros(6)), mass=np.ones((B, 1)), inertia=I0,
+                restitution=np.zeros((B, 1)), fric=np.zeros((B, 1)), fext=np.concatenate([0.5 * dirs, np.zeros((B, 3))], 1)[:, None],
+                shape_type=np.ones((B, 1), np.int32), shape_prm=one([0.6, 0, 0]), mesh_id=np.zeros((B, 1), np.int32),
+                meshes=[(0.6 * v, f)], mesh_vgrad=[v],
+                Je=np.tile(np.concatenate([np.zeros((3, 3)), np.eye(3)], 1), (B, 1, 1)), no_contact=np.zeros((1, 1), np.uint8))

@@ -216,6 +216,8 @@ typedef struct DssWorld {
     double *igr_qsdf;        /* [4][igr_qcap] network outputs */
     double *igr_qgrad;       /* [2][igr_qcap][3] d phi / d xyz of the gradient lists */
     int *igr_qn;             /* [2 (DSS_IGR_ROUNDS + 2)] list lengths: value and gradient list of every round */
+    void **igr_ev;           /* optional hipEvent_t [4 (DSS_IGR_ROUNDS + 1)] in HOST memory: (start, stop) around the value-list and the
+                                gradient-list evaluation of every round (bench roofline); NULL in production */
 } DssWorld;
 
 #define DSS_N_ACTIVE_OVERFLOW (1 << 30)   /* set in n_active[0] once any scene's overflow word is non-zero */

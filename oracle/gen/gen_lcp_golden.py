@@ -110,6 +110,28 @@ def main():
         calls, _ = capture_engine_lcps(bodies, joints, 3, pick=pick)
         for i, (kw, ops) in enumerate(calls):
             run_case("lcp_%s_%d" % (tag, i), *ops, max_iter=kw["max_iter"], seed=20 + i)
+    # BASELINE configs[2] sizes: 8 bodies (nz = 48, neq = 6).  Seven aligned unit boxes stacked on
+    # the floor make 4 contacts per directed pair = 56 contacts, nineq = 560; four stacked + three resting apart 40 contacts, nineq = 400.
+    bodies, joints, _ = scenes.box_stack(nbox=7, seed=5, requires_grad=False, vel_scale=0.2, push=0.5, aligned=True)
+    calls, _ = capture_engine_lcps(bodies, joints, 1, pick=[0])
+    for i, (kw, ops) in enumerate(calls):
+        run_case("lcp_stack7_%d" % i, *ops, max_iter=kw["max_iter"], seed=30 + i)
+    bodies, joints, _ = scenes.box_stack(nbox=7, seed=6, requires_grad=False, vel_scale=0.2, push=0.5, aligned=True, stacked=4)
+    calls, _ = capture_engine_lcps(bodies, joints, 1, pick=[0])
+    for i, (kw, ops) in enumerate(calls):
+        run_case("lcp_stack4p3_%d" % i, *ops, max_iter=kw["max_iter"], seed=40 + i)
+    # an infeasible problem: rows g x <= -1 and -g x <= -1 cannot both hold.  The reference returns its best iterate
+    # silently (verbose = -1) where verbose >= 0 would print INACC_ERR (batch.py:165-167, 229-230): residual > 1
+    g = torch.Generator().manual_seed(77)
+    nB, nz, m = 2, 6, 4
+    L = torch.randn(nB, nz, nz, generator=g, dtype=torch.double)
+    Q = L @ L.transpose(1, 2) + torch.eye(nz, dtype=torch.double)
+    p = torch.randn(nB, nz, generator=g, dtype=torch.double)
+    G0 = torch.randn(nB, m, nz, generator=g, dtype=torch.double)
+    G = torch.cat([G0, -G0], dim=1)
+    h = -torch.ones(nB, 2 * m, dtype=torch.double)
+    F = torch.zeros(nB, 2 * m, 2 * m, dtype=torch.double)
+    run_case("lcp_infeasible", Q, p, G, h, torch.tensor([]), torch.tensor([]), F, max_iter=20, seed=77, meta={"inaccurate": np.int64(1)})
 
 
 if __name__ == "__main__":

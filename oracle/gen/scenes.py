@@ -7,7 +7,9 @@ import torch
 
 
 def box_stack(nbox=3, seed=0, floor_dims=(4.0, 1.0, 4.0), mu=0.5, rest=0.0, gap=5e-4, requires_grad=True,
-              vel_scale=0.0, push=0.0):
+              vel_scale=0.0, push=0.0, aligned=False, stacked=None):
+    """aligned: unit cubes without yaw or lateral offsets (4 contacts per directed pair, the count SURVEY.md section 6 saw);
+    stacked: only the first `stacked` boxes form the tower, the others rest on the floor next to it (needs a wide floor)."""
     from sdf_physics.physics3d.bodies import SDFBox
     from sdf_physics.physics3d.constraints import TotalConstraint3D
     from sdf_physics.physics3d.forces import Gravity3D
@@ -23,6 +25,13 @@ def box_stack(nbox=3, seed=0, floor_dims=(4.0, 1.0, 4.0), mu=0.5, rest=0.0, gap=
             dims.requires_grad_()
         off = -0.05 + 0.1 * torch.rand(2, generator=g, dtype=torch.double)
         yaw = 0.2 * torch.rand(1, generator=g, dtype=torch.double).item()
+        if aligned:
+            dims = torch.ones(3, dtype=torch.double, requires_grad=requires_grad)
+            off, yaw = torch.zeros(2, dtype=torch.double), 0.0
+        k = len(bodies) - 1
+        if stacked is not None and k >= stacked:      # beside the tower, on the floor
+            off = torch.tensor([1.5 * (k - stacked + 1) * (1 if k % 2 else -1), 0.0], dtype=torch.double)
+            y = 0.0
         yc = y + gap + dims[1].item() / 2
         pos = torch.tensor([0, yaw, 0, off[0].item(), yc, off[1].item()], dtype=torch.double)
         vel = vel_scale * (torch.rand(6, generator=g, dtype=torch.double) - 0.5)
@@ -222,3 +231,17 @@ def levelset_cylinder(requires_grad=True):
     c = SDFCylinder([0.0, 0.2505, 0.0], r, h, vel=[0, 0, 1.0, 0.5, 0, 0], restitution=0.1, fric_coeff=0.3)
     c.add_force(Gravity3D())
     return [f, c], [TotalConstraint3D(f)], [r, h]
+
+
+def fast_sphere(vy=-60.0, y0=1.2, rad=0.5, floor_dims=(4.0, 1.0, 4.0), mu=0.25, rest=0.5, requires_grad=True):
+    """A sphere thrown at the floor so fast that no halving of dt lands it inside the contact band (eps = 1e-3) without
+    penetrating (> tol): with strict_no_penetration=False the reference gives up halving once dt < dt/2^10 and goes on with
+    the penetrating contacts as they are (world.py:345-347)."""
+    from sdf_physics.physics3d.bodies import SDFBox, SDFSphere
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+    rad_t = torch.tensor(float(rad), dtype=torch.double, requires_grad=requires_grad)
+    floor = SDFBox([0, -floor_dims[1] / 2, 0], list(floor_dims), custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    ball = SDFSphere([0, y0, 0], rad_t, vel=[0, 0, 0, 0.3, vy, 0], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
+    ball.add_force(Gravity3D())
+    return [floor, ball], [TotalConstraint3D(floor)], [rad_t]

@@ -173,3 +173,27 @@ def test_tape_overflow_is_a_capacity_error():
     with pytest.raises(RuntimeError, match="max_sub"):
         for _ in range(8):
             E.step()
+
+
+def test_escape_from_endless_halving_keeps_the_penetrating_contacts_like_the_reference():
+    """strict_no_penetration=False and a sphere too fast for any halving of dt to land in the contact band: once
+    dt < dt / 2^10 the reference goes on with the contacts as they are (world.py:345-347) -- every contact of the penetrating
+    direction, unthinned (here 6 where the thinned set would be smaller), none from the reverse direction, no time-of-contact
+    bookkeeping, and no gradient through their geometry (they were computed under no_grad)."""
+    g, E = make("rollout_fast_sphere", 2, max_sub=32)
+    assert not bool(g["strict_no_pen"])
+    R.rollout_and_sweep(E, 3)
+    assert (E.get("nsub") == len(g["traj_t"])).all(), E.get("nsub")
+    k = len(g["traj_t"]) - 1
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-7
+    tnc, tg, tb, tf = E.get("tp_nc"), E.get("tp_geom"), E.get("tp_body"), E.get("tp_face")
+    for j in range(1, k + 1):
+        n = int(g["traj_nc"][j - 1])
+        assert int(tnc[j, 0]) == n, (j, int(tnc[j, 0]), n)
+        if n:
+            assert (tg[j, 0][9, :n] > float(g["tol"])).any(), "the kept contacts penetrate"
+            assert [tuple(r) for r in tb[j, 0][:, :n].T] == [tuple(r) for r in g["traj_body"][j - 1][:n]]
+            assert (tf[j, 0][:n] < 0).all(), "contacts of a penetrating direction carry no geometry adjoint"
+            a = np.sort(tg[j, 0][3:6, :n].T, axis=0); b = np.sort(g["traj_geom"][j - 1][:n, 3:6], axis=0)
+            assert np.abs(a - b).max() < 1e-7
+    R.check_gradients(E, g, tol=1e-5)

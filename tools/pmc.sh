@@ -1,30 +1,61 @@
 #!/bin/bash
-# Dev aid (GPU box): HBM-side traffic of the bench kernels from rocprofv3 PMC counters, FETCH_SIZE and WRITE_SIZE in
-# SEPARATE passes (MI355X guide, HBM section), plus a kernel-stats pass of the same command.
-#   -> gpurun_out/r1_pmc_traffic.json, gpurun_out/r1_kernel_stats.csv   (copy into profiles/ to have them judged)
+# Dev aid (GPU box): per-kernel counters of the bench command from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+# SEPARATE passes, MI355X guide, HBM section; fp64 instruction counts; VALU / MFMA busy cycles), plus a kernel-stats pass of
+# the same command.  Usage: tools/pmc.sh <config> <steps> [batch]
+#   -> gpurun_out/r2_pmc_config<N>.json (stamped with the library's hash: bench.py reports its numbers only for that build)
+#      gpurun_out/r2_kernel_stats_config<N>.csv        (copy both into profiles/ to have them judged)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-STEPS=${1:-5}
-rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/kstats
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python bench.py --steps $STEPS --warmup 1 > gpurun_out/pmc_f.log 2>&1
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python bench.py --steps $STEPS --warmup 1 > gpurun_out/pmc_w.log 2>&1
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python bench.py --steps 20 --warmup 3 > gpurun_out/kstats.log 2>&1
-python - <<PY
-import csv, glob, json, collections, shutil
-out = collections.OrderedDict()
-for tag, d in (("FETCH_SIZE", "pmc_f"), ("WRITE_SIZE", "pmc_w")):
-    f = glob.glob("gpurun_out/%s/*/*_counter_collection.csv" % d)[0]
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == tag:
-            acc[r["Kernel_Name"][:50]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        if "anonymous" not in k: continue
-        e = out.setdefault(k, {})
-        e[tag + "_KB_avg"] = sum(v) / len(v)
-        e["dispatches"] = len(v)
-    shutil.copy(f, "gpurun_out/r1_pmc_%s_sample.csv" % ("fetch" if tag == "FETCH_SIZE" else "write"))
-json.dump(out, open("gpurun_out/r1_pmc_traffic.json", "w"), indent=1)
-shutil.copy(glob.glob("gpurun_out/kstats/*/*kernel_stats.csv")[0], "gpurun_out/r1_kernel_stats.csv")
-for k, v in out.items(): print(k, v)
+CFG=${1:-3}
+STEPS=${2:-5}
+BATCH=${3:+--batch $3}
+OUT=gpurun_out/pmc_c$CFG
+rm -rf $OUT && mkdir -p $OUT
+pass() {   # name, counters...
+    local name=$1; shift
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu $BATCH > $OUT/$name.log 2>&1 || echo "pass $name failed (see $OUT/$name.log)"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64
+pass busy SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -- python3 bench.py --config $CFG --steps $((STEPS * 2)) --warmup 2 --no-cpu $BATCH > $OUT/kstats.log 2>&1
+python3 - "$CFG" "$OUT" <<'PY'
+import collections, csv, glob, hashlib, json, shutil, sys
+cfg, out_dir = sys.argv[1], sys.argv[2]
+kern = collections.OrderedDict()
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+for d in ("fetch", "write", "f64", "busy", "mfma"):
+    fs = glob.glob("%s/%s/*/*_counter_collection.csv" % (out_dir, d))
+    if not fs:
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        e = kern.setdefault(k, {})
+        for c, v in cs.items():
+            e[("%s_KB_avg" if c in ("FETCH_SIZE", "WRITE_SIZE") else "%s_avg") % c] = sum(v) / len(v)
+            e["dispatches"] = len(v)
+for k, e in kern.items():
+    # SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD summed over the chip; SQ_BUSY_CYCLES per shader engine: report the plain
+    # ratio the round-1 profiles used (VALU-issue cycles / wave-resident cycles) as an indication, not an absolute
+    if "SQ_ACTIVE_INST_VALU_avg" in e and e.get("SQ_WAVE_CYCLES_avg"):
+        e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU_avg"] / e["SQ_WAVE_CYCLES_avg"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in e and e.get("GRBM_GUI_ACTIVE_avg"):
+        # busy cycles are summed over the 1024 SIMDs of the chip (MI355X guide): fraction of the kernel's cycles the matrix
+        # pipes were busy, averaged over SIMDs
+        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (e["GRBM_GUI_ACTIVE_avg"] * 1024.0)
+lib = "diffsdfsim_amd/csrc/libdiffsdfsim_hip.so"
+res = {"config": int(cfg), "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16], "kernels": kern}
+json.dump(res, open("gpurun_out/r2_pmc_config%s.json" % cfg, "w"), indent=1)
+ks = glob.glob("%s/kstats/*/*kernel_stats.csv" % out_dir)
+if ks:
+    shutil.copy(ks[0], "gpurun_out/r2_kernel_stats_config%s.csv" % cfg)
+for k, v in kern.items():
+    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
 PY
-tail -1 gpurun_out/kstats.log | cut -c1-400
+tail -1 $OUT/kstats.log | cut -c1-600
+# the raw per-dispatch tables are large (gpurun merges at most 64 MiB back): keep the logs and the summaries only
+for d in fetch write f64 busy mfma kstats; do rm -rf $OUT/$d; done
