@@ -27,3 +27,17 @@ __device__ __forceinline__ double dss_uniform(double x)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 #endif
+
+// A big by-value kernel argument (DssWorld, ~1 KB) whose address is handed to non-inlined device functions is copied by the
+// compiler into every lane's private scratch memory (64 KB per wavefront of stores at kernel entry, and every later field
+// access a scratch load).  Referring to it where it already lies -- the kernarg segment, readable by every lane -- avoids the
+// copy.  `arg` must be the kernel's FIRST parameter (offset 0 of the segment).
+#if defined(DSS_EMU)
+#define DSS_KERNARG_REF(T, name, arg) const T &name = arg
+#define DSS_KERNARG_REF_AT(T, name, arg, offset) const T &name = arg
+#else
+#define DSS_KERNARG_REF(T, name, arg) const T &name = *(const T *)__builtin_amdgcn_kernarg_segment_ptr(); (void)arg
+// a later parameter: `offset` = its byte offset in the segment (parameters are laid out in order at their natural alignment)
+#define DSS_KERNARG_REF_AT(T, name, arg, offset) \
+    const T &name = *(const T *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + (offset)); (void)arg
+#endif

@@ -568,8 +568,9 @@ union NpScratch {
     ScratchT<BlockGroup> blk;
     ScratchT<WaveGroup> wav[BlockGroup::NW];
 };
-template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W)
+template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W_arg)
 {
+    DSS_KERNARG_REF(DssWorld, W, W_arg);
     __shared__ NpScratch S;
     __shared__ int s_item;
     const int cap = W.B * npairs_of(W.nb), seg = DEFERRED ? 2 : 0;

@@ -608,8 +608,9 @@ __device__ void advance(const DssWorld &W, ScratchT<G> &S, int it, int round, in
     }
 }
 
-__global__ void __launch_bounds__(G::BT) igr_advance_kernel(DssWorld W, int round, int last_round)
+__global__ void __launch_bounds__(G::BT) igr_advance_kernel(DssWorld W_arg, int round, int last_round)
 {
+    DSS_KERNARG_REF(DssWorld, W, W_arg);
     __shared__ ScratchT<G> S;
     int n = W.n_pairs[6];
     if (n > W.igr_items_cap) n = W.igr_items_cap;

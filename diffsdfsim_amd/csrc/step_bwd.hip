@@ -236,8 +236,11 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
 // list twice on the matrix cores (d/dxyz, d/dlatent), igr_records turns the answers into the records of one contact.
 __device__ inline bool in_cube3(const double *p, double s) { return fabs(p[0]) <= s && fabs(p[1]) <= s && fabs(p[2]) <= s; }
 
-__global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W, DssAdjoint A)
+__global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W_arg, DssAdjoint A_arg)
 {
+    static_assert(sizeof(DssWorld) % 8 == 0, "the adjoint descriptor follows the world descriptor without padding");
+    DSS_KERNARG_REF(DssWorld, W, W_arg);
+    DSS_KERNARG_REF_AT(DssAdjoint, A, A_arg, sizeof(DssWorld));
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
     int k, act, init;
     SlotView v;
@@ -352,8 +355,11 @@ __device__ inline void contact_sums(const int *body, int MX, int nc, int nb, con
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
+__global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint A_arg)
 {
+    static_assert(sizeof(DssWorld) % 8 == 0, "the adjoint descriptor follows the world descriptor without padding");
+    DSS_KERNARG_REF(DssWorld, W, W_arg);
+    DSS_KERNARG_REF_AT(DssAdjoint, A, A_arg, sizeof(DssWorld));
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
     int k, act, init;
     SlotView v;
@@ -607,8 +613,11 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W, DssAdjoint A)
     if (lane == 0) A.bw_nc[sc] = v.nc_k;
 }
 
-__global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W, DssAdjoint A)
+__global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W_arg, DssAdjoint A_arg)
 {
+    static_assert(sizeof(DssWorld) % 8 == 0, "the adjoint descriptor follows the world descriptor without padding");
+    DSS_KERNARG_REF(DssWorld, W, W_arg);
+    DSS_KERNARG_REF_AT(DssAdjoint, A, A_arg, sizeof(DssWorld));
     const int sc = blockIdx.x, lane = threadIdx.x, nb = W.nb, MX = W.maxc;
     if (!A.bw_active[sc]) return;
     const int k = A.cur_slot[sc];

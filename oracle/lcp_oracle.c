@@ -383,12 +383,16 @@ int lcp_oracle_forward(const double *Q, const double *p, const double *G, const 
     int worst = 0;
 #pragma omp parallel for schedule(dynamic) reduction(max : worst)
     for (int i = 0; i < nbatch; ++i) {
+        double best = 0.0;
         int rc = lcp_oracle_forward1(Q + (size_t)i * nz * nz, p + (size_t)i * nz, G + (size_t)i * nineq * nz,
                                      h + (size_t)i * nineq, A + (size_t)i * neq * nz, b + (size_t)i * neq,
                                      F + (size_t)i * nineq * nineq, nz, nineq, neq, eps, not_improved_lim,
                                      max_iter, check_spd, zhat + (size_t)i * nz, lam + (size_t)i * nineq,
                                      slack + (size_t)i * nineq, nu + (size_t)i * neq,
-                                     iters ? iters + i : NULL, NULL);
+                                     iters ? iters + i : NULL, &best);
+        /* status 4: the best residual stayed above 1 -- where the reference prints INACC_ERR if verbose >= 0
+           (batch.py:165-167, 229-230); the engine's verbose = -1 keeps it silent, the iterate is returned either way */
+        if (rc == 0 && best > 1.0) rc = 4;
         if (status) status[i] = rc;
         if (rc > worst) worst = rc;
     }

@@ -27,6 +27,7 @@ struct emu_uint3 { unsigned x, y, z; };
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__
 #define __launch_bounds__(...)
 #define __align__(n)
 #define __restrict__
@@ -47,6 +48,7 @@ struct Fiber {
     bool done = false;
 };
 struct State {
+    int bar_count = 0, bar_gen = 0, alive = 0;   // block barrier: arrivals, generation, fibers still running
     std::vector<Fiber> fibers;
     ucontext_t sched;
     int cur = 0;
@@ -70,6 +72,8 @@ inline void trampoline()
     State &s = st();
     s.body();
     s.fibers[s.cur].done = true;
+    --s.alive;
+    if (s.alive > 0 && s.bar_count == s.alive) { s.bar_count = 0; ++s.bar_gen; }   // the others were waiting for this one
     swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
 inline void run_block(unsigned nthreads)
@@ -77,6 +81,7 @@ inline void run_block(unsigned nthreads)
     State &s = st();
     s.fibers.clear();
     s.fibers.resize(nthreads);
+    s.bar_count = 0; s.bar_gen = 0; s.alive = (int)nthreads;
     s.slots.assign(nthreads, 0);
     for (unsigned t = 0; t < nthreads; ++t) {
         Fiber &f = s.fibers[t];
@@ -133,7 +138,16 @@ template <class T> inline T shfl_from(T v, int src)
 #define blockDim (dss_emu::bdim())
 #define gridDim (dss_emu::gdim())
 
-inline void __syncthreads() { dss_emu::yield(); }
+// a true workgroup barrier (wavefronts of one workgroup may run different code between barriers): wait until every fiber
+// that is still running has arrived
+inline void __syncthreads()
+{
+    dss_emu::State &s = dss_emu::st();
+    const int gen = s.bar_gen;
+    if (++s.bar_count == s.alive) { s.bar_count = 0; ++s.bar_gen; }
+    else while (s.bar_gen == gen) dss_emu::yield();
+    dss_emu::yield();
+}
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return dss_emu::shfl_from(v, (dss_emu::st().cur & 63) ^ mask); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return dss_emu::shfl_from(v, src); }
 template <class T> inline T __shfl_up(T v, int d, int = 64)
@@ -151,13 +165,14 @@ inline int emu_block_reduce(int pred, int mode)
 {
     dss_emu::State &s = dss_emu::st();
     s.slots[s.cur] = (uint64_t)(pred != 0);
-    dss_emu::yield();
+    __syncthreads();
     int acc = (mode == 1) ? 1 : 0;
     for (size_t i = 0; i < s.slots.size(); ++i) {
+        if (s.fibers[i].done) continue;
         int v = (int)s.slots[i];
         if (mode == 0) acc |= v; else if (mode == 1) acc &= v; else acc += v;
     }
-    dss_emu::yield();
+    __syncthreads();
     return acc;
 }
 inline int __syncthreads_or(int p) { return emu_block_reduce(p, 0); }

@@ -28,7 +28,7 @@ def run_fwd(g, max_iter, check_spd=True):
 def test_forward_matches_reference_golden(path):
     g = load_lcp(path)
     z, lam, s, nu, it, st = run_fwd(g, int(g["max_iter"]))
-    assert (st == 0).all(), st
+    assert (st == (4 if "inaccurate" in g else 0)).all(), st      # DSS_LCP_INACCURATE: the INACC_ERR condition (batch.py:165-167)
     assert rel(z, g["zhat"]) < 1e-9
     assert rel(s, g["slack"]) < 1e-6
     assert rel(lam, g["lam"]) < 1e-3  # multipliers: see tests/test_oracle_lcp.py

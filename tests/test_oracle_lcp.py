@@ -10,7 +10,7 @@ from oracle import lcp_oracle as O
 def test_oracle_forward_matches_reference(path):
     g = load_lcp(path)
     z, lam, s, nu, it, st = O.forward(g["Q"], g["p"], g["G"], g["h"], g["A"], g["b"], g["F"], max_iter=int(g["max_iter"]))
-    assert (st == 0).all()
+    assert (st == (4 if "inaccurate" in g else 0)).all()      # DSS_LCP_INACCURATE: the INACC_ERR condition (batch.py:165-167)
     # primal solution (velocities): unique -> tight.  Multipliers are only unique up to the null space
     # of G^T on redundant contact manifolds; the reference itself moves by ~1e-5 there under 1-ulp changes.
     assert rel(z, g["zhat"]) < 1e-10
