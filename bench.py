@@ -258,7 +258,8 @@ def main():
         e.record()
     import ctypes
     igr_ev_arr = (ctypes.c_void_p * nev)(*[e.cuda_event for e in igr_events]) if neural else None
-    igr_ms, igr_pts = [], []           # per sampled launch: duration, (value points, gradient points)
+    igr_attempts = []
+    igr_ms, igr_pts, igr_est = [], [], []           # per sampled launch: duration, (points, list), the grid-size hint it ran with
     qn_total = torch.zeros(2 * (abi.IGR_ROUNDS + 2), dtype=torch.int64, device=dev) if neural else None
     torch.cuda.synchronize()
     lo = E.arr["nsub"].clone()
@@ -277,6 +278,7 @@ def main():
             E.W.ev_lcp_start, E.W.ev_lcp_stop = a.cuda_event, b.cuda_event
             E.W.ev_np_start, E.W.ev_np_stop = c.cuda_event, d.cuda_event
             sample = neural and len(ev) % IGR_EV_EVERY == 0
+            hint_was = E.igr_hint.copy() if (sample and E.igr_hint is not None) else None
             E.W.igr_ev = ctypes.cast(igr_ev_arr, ctypes.c_void_p) if sample else None
             E._check(L.dss_step_attempt(ctypes.byref(E.W), ctypes.c_void_p(E.be.ptr(E.lcp_ws)),
                                         ctypes.c_size_t(E.lcp_ws_bytes), E.be.stream()), "dss_step_attempt")
@@ -286,13 +288,16 @@ def main():
             n = E.be.read_int(E.arr["n_active"])        # (the one host read of an attempt; the stream is idle afterwards)
             if n & (1 << 30):
                 E._raise_overflow()
+            E._update_igr_hint(k == 0, n == 0)
             if sample:
+                igr_attempts.append((len(ev) - 1, len(igr_ms)))
                 qn = E.get("igr_qn")
                 for r in range(1, abi.IGR_ROUNDS + 1):
                     for l in range(2):
                         if qn[2 * r + l] > 0:
                             igr_ms.append(igr_events[4 * r + 2 * l].elapsed_time(igr_events[4 * r + 2 * l + 1]))
                             igr_pts.append((int(qn[2 * r + l]), l))
+                            igr_est.append(int(hint_was[2 * r + l]) if hint_was is not None else -1)
             k += 1
         return k
 
@@ -383,6 +388,12 @@ def main():
                  "largest_decile_launches": {"TFLOPs": float(flops[big].sum() / (ms[big].sum() * 1e-3) / 1e12), "avg_points": float(np.mean([n for (n, l), b in zip(igr_pts, big) if b]))},
                  "points_evaluated": {"value_only": nv, "with_gradient": ng, "per_step": (nv + ng) / K},
                  "mfma_busy_frac": pmc_sum(pmc, "mfma_busy_frac", "igr_query_kernel"),
+                 "sampled_attempts": {"detection_ms_mean": float(np.mean([det_ms[a] for a, _ in igr_attempts])),
+                                      "network_ms_mean": float(ms.sum() / max(1, len(igr_attempts))),
+                                      "detection_ms_all_attempts_mean": float(det_ms.mean())},
+                 "detection_ms_first_attempts": [round(float(x), 2) for x in det_ms[:48]],
+                 "slowest_launches": [{"ms": float(ms[i]), "points": igr_pts[i][0], "list": "grad" if igr_pts[i][1] else "value", "hint": igr_est[i]}
+                                      for i in np.argsort(-ms)[:6]],
                  "note": "network evaluations of the neural narrow phase, one launch per query round and list; flops = 2 x 115456 MAC per "
                          "point (x4 with the three xyz tangents); events around one attempt in %d" % IGR_EV_EVERY}
         dominant, other = r_igr, r_det

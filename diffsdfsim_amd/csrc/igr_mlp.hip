@@ -183,7 +183,7 @@ igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, 
 }
 
 template <int NW, int NG, int MODE>
-void launch(const Query &Q, const DssIgrNet &N, int n_cap, hipStream_t stream)
+void launch(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t stream)
 {
     constexpr int PTS = (MODE == MODE_VALUE ? 16 : 4) * NG;
     const size_t lds = (size_t)16 * NG * LDX * sizeof(double);
@@ -192,21 +192,34 @@ void launch(const Query &Q, const DssIgrNet &N, int n_cap, hipStream_t stream)
         (void)hipFuncSetAttribute((const void *)igr_query_kernel<NW, NG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
     long tiles = ((long)n_cap + PTS - 1) / PTS;
-    // a list whose length is only known on the device gets a grid that fills the chip (2 workgroups per CU and a few
-    // rounds); surplus workgroups leave at once
-    const long cap = Q.n_dev ? 256L * 2 * 4 : (1L << 30);
-    if (tiles > cap) tiles = cap;
+    if (Q.n_dev) {
+        // The length is only known on the device.  The grid is persistent over the tiles, so ANY size is correct; what it
+        // costs is dispatch time (a workgroup that finds nothing to do still takes ~0.1 us to launch: 2048 of them are
+        // 200 us, several times the evaluation of a small list).  `est` = the caller's expectation (the length the same
+        // list had in the previous detection), or < 0: fill the chip.
+        // (twice the expectation, and never fewer than 128 workgroups: a list that turns out far longer than expected --
+        // the step in which bodies first touch -- must not crawl through a handful of workgroups)
+        long want = est < 0 ? 512 : (2L * est + PTS - 1) / PTS + 2;
+        if (want < 128) want = 128;
+        const long cap = 256L * 2 * 4;
+        tiles = want < tiles ? want : tiles;
+        if (tiles > cap) tiles = cap;
+    }
     if (tiles < 1) tiles = 1;
     hipLaunchKernelGGL((igr_query_kernel<NW, NG, MODE>), dim3((unsigned)tiles), dim3(64 * NW), lds, stream, Q, N.W0, N.b0, N.Wp,
                        N.bh, N.W8, N.b8);
 }
 
-template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_cap, hipStream_t stream)
+template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t stream)
 {
-    // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 4 row groups, halving the L2
-    // weight traffic; small ones: 2 waves x 2 groups so the grid still covers the chip.  Both give bit-identical results.
-    if (n_cap >= 16 * 1024) launch<4, 4, MODE>(Q, N, n_cap, stream);
-    else launch<2, 2, MODE>(Q, N, n_cap, stream);
+    // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 4 row groups, which quarters
+    // the L2 weight traffic per point; small ones (a Frank-Wolfe round moves a few points per item): one row group per
+    // workgroup, a quarter of the latency of a pass and four times as many workgroups to spread over the chip.
+    // All variants give bit-identical results (a point's row never mixes with its tile-mates').
+    const int n = Q.n_dev ? (est < 0 ? n_cap : est) : n_cap;
+    if (n >= 16 * 1024) launch<4, 4, MODE>(Q, N, n_cap, est, stream);
+    else if (n >= 2 * 1024) launch<2, 2, MODE>(Q, N, n_cap, est, stream);
+    else launch<4, 1, MODE>(Q, N, n_cap, est, stream);
 }
 
 inline bool net_ok(const DssIgrNet *N) { return N && N->W0 && N->b0 && N->Wp && N->bh && N->W8 && N->b8; }
@@ -216,12 +229,12 @@ inline bool net_ok(const DssIgrNet *N) { return N && N->W0 && N->b0 && N->Wp && 
 namespace dss {
 // used by the neural narrow phase (narrowphase_igr.hip) and the reverse sweep: one evaluation round over a device-side list
 int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
-                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream)
+                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream, int est)
 {
     Query Q{pts, lat_idx, latents, lat_stride, n_dev, n_cap, sdf, grad};
-    if (mode == MODE_VALUE) launch_mode<MODE_VALUE>(Q, N, n_cap, stream);
-    else if (mode == MODE_LATENT) launch_mode<MODE_LATENT>(Q, N, n_cap, stream);
-    else launch_mode<MODE_XYZ>(Q, N, n_cap, stream);
+    if (mode == MODE_VALUE) launch_mode<MODE_VALUE>(Q, N, n_cap, est, stream);
+    else if (mode == MODE_LATENT) launch_mode<MODE_LATENT>(Q, N, n_cap, est, stream);
+    else launch_mode<MODE_XYZ>(Q, N, n_cap, est, stream);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 }  // namespace dss
@@ -235,7 +248,7 @@ int dss_igr_query(const double *pts, const double *latent, const double *W0, con
 {
     if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
     const DssIgrNet N{W0, b0, Wp, bh, W8, b8};
-    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_XYZ, sdf, grad, (hipStream_t)stream);
+    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_XYZ, sdf, grad, (hipStream_t)stream, -1);
 }
 
 // The same network evaluation with the tangents seeded on the latent code instead of the point: grad [n][3] =
@@ -246,7 +259,7 @@ int dss_igr_query_latent_grad(const double *pts, const double *latent, const dou
 {
     if (!pts || !latent || !W0 || !b0 || !Wp || !bh || !W8 || !b8 || !sdf || !grad || n <= 0) return DSS_E_BADARG;
     const DssIgrNet N{W0, b0, Wp, bh, W8, b8};
-    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_LATENT, sdf, grad, (hipStream_t)stream);
+    return dss::launch_igr_list(N, pts, nullptr, latent, 2, nullptr, n, MODE_LATENT, sdf, grad, (hipStream_t)stream, -1);
 }
 
 int dss_igr_query_list(const DssIgrNet *net, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
@@ -255,7 +268,7 @@ int dss_igr_query_list(const DssIgrNet *net, const double *pts, const int *lat_i
     if (!net_ok(net) || !pts || !latents || !sdf || n_cap <= 0 || lat_stride < 2) return DSS_E_BADARG;
     if (mode != MODE_VALUE && mode != MODE_XYZ && mode != MODE_LATENT) return DSS_E_BADARG;
     if (mode != MODE_VALUE && !grad) return DSS_E_BADARG;
-    return dss::launch_igr_list(*net, pts, lat_idx, latents, lat_stride, n_dev, n_cap, mode, sdf, grad, (hipStream_t)stream);
+    return dss::launch_igr_list(*net, pts, lat_idx, latents, lat_stride, n_dev, n_cap, mode, sdf, grad, (hipStream_t)stream, -1);
 }
 
 }  // extern "C"

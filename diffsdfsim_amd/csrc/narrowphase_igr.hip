@@ -28,7 +28,7 @@
 
 namespace dss {
 int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
-                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream);
+                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream, int est);
 }
 
 namespace {
@@ -633,7 +633,10 @@ int launch_igr_rounds(const DssWorld &W, hipStream_t stream)
     const int rounds = W.igr_rounds > 0 ? W.igr_rounds : DSS_IGR_ROUNDS;
     if (rounds > DSS_IGR_ROUNDS) return DSS_E_BADARG;
     (void)hipMemsetAsync(W.igr_qn, 0, (size_t)2 * (DSS_IGR_ROUNDS + 2) * sizeof(int), stream);
-    const int grid = W.igr_items_cap < 256 * 4 ? W.igr_items_cap : 256 * 4;
+    // one workgroup per item; with the caller's expectation (items of the previous detection) no more than that plus slack --
+    // the kernel strides over the list, so any grid is correct (see igr_mlp.hip on what an idle workgroup costs)
+    int grid = W.igr_items_cap < 256 * 4 ? W.igr_items_cap : 256 * 4;
+    if (W.igr_hint) { int want = 2 * W.igr_hint[0] + 8; if (want < 64) want = 64; if (want < grid) grid = want; }
     for (int r = 0; r <= rounds; ++r) {
         if (r > 0) {
             const int set = r & 1;
@@ -642,7 +645,7 @@ int launch_igr_rounds(const DssWorld &W, hipStream_t stream)
                 if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l], stream);
                 const int rc = launch_igr_list(W.igr, W.igr_qpts + o * 3, W.igr_qlat + o, W.shape_prm, 3, W.igr_qn + 2 * r + l, W.igr_qcap,
                                                l == L_VALUE ? DSS_IGR_VALUE : DSS_IGR_XYZ, W.igr_qsdf + o,
-                                               W.igr_qgrad + (size_t)set * W.igr_qcap * 3, stream);
+                                               W.igr_qgrad + (size_t)set * W.igr_qcap * 3, stream, W.igr_hint ? W.igr_hint[2 * r + l] : -1);
                 if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l + 1], stream);
                 if (rc) return rc;
             }

@@ -739,16 +739,16 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W_arg, DssAdjoint
 #if DSS_ALL_SHAPES
 namespace dss {
 int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
-                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream);
+                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream, int est);
 void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stream)
 {
     if (W.igr.W0 && A.igr_bw_idx) {
         const int cap = W.B * 2 * W.maxc;
         (void)hipMemsetAsync(A.igr_bw_n, 0, sizeof(int), stream);
         hipLaunchKernelGGL(bwd_igr_prep_kernel, dim3(W.B), dim3(64), 0, stream, W, A);
-        launch_igr_list(W.igr, A.igr_bw_pts, A.igr_bw_lat, W.shape_prm, 3, A.igr_bw_n, cap, DSS_IGR_XYZ, A.igr_bw_sdf, A.igr_bw_grad, stream);
+        launch_igr_list(W.igr, A.igr_bw_pts, A.igr_bw_lat, W.shape_prm, 3, A.igr_bw_n, cap, DSS_IGR_XYZ, A.igr_bw_sdf, A.igr_bw_grad, stream, W.B * 8);
         launch_igr_list(W.igr, A.igr_bw_pts, A.igr_bw_lat, W.shape_prm, 3, A.igr_bw_n, cap, DSS_IGR_LATENT, A.igr_bw_sdf + cap,
-                        A.igr_bw_grad + (size_t)cap * 3, stream);
+                        A.igr_bw_grad + (size_t)cap * 3, stream, W.B * 8);
     }
     hipLaunchKernelGGL(bwd_pre_kernel, dim3(W.B), dim3(64), 0, stream, W, A);
 }

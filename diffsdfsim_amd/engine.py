@@ -184,6 +184,13 @@ class BatchEngine:
         for name, kind in abi.FIELDS:
             if kind in ("pd", "pi", "pb"):
                 setattr(W, name, self.be.ptr(self.arr[name]) if name in self.arr else None)
+        # neural narrow phase: what the previous detection found (host side), which sizes the grids of the next one
+        self.igr_hint = None
+        import os
+        if self.igr_items_cap > 0 and not os.environ.get("DSS_NO_IGR_HINT"):
+            self.igr_hint = np.full(2 * (abi.IGR_ROUNDS + 2), -1, np.int32)
+            self.igr_hint[0] = self.igr_items_cap
+            W.igr_hint = self.igr_hint.ctypes.data
         self.W = W
         L = self.be.lib
         L.dss_world_sizeof.restype = ctypes.c_size_t
@@ -215,6 +222,19 @@ class BatchEngine:
         if rc != 0:
             raise RuntimeError("%s failed with code %d" % (what, rc))
 
+    def _update_igr_hint(self, first_attempt, step_ends):
+        """What the next detection should expect (DssWorld.igr_hint: it sizes launch grids, nothing else).  Within an outer
+        step the set of active scenes only shrinks from attempt to attempt, so a retry expects what the attempt before it
+        found; the first attempt of a step, with every scene active again, expects what the first attempt of the previous
+        step found.  Two small device reads next to the one the attempt loop makes anyway."""
+        if self.igr_hint is None:
+            return
+        now = self.get("igr_qn").astype(np.int32)
+        now[0] = int(self.get("n_pairs")[6])
+        if first_attempt:
+            self._igr_first = now.copy()
+        self.igr_hint[:] = self._igr_first if step_ends else now
+
     def _set_active(self, v):
         a = self.arr["active"]
         a[...] = v
@@ -235,6 +255,7 @@ class BatchEngine:
             n = self.be.read_int(self.arr["n_active"])
             if n & abi.N_ACTIVE_OVERFLOW:
                 self._raise_overflow()
+            self._update_igr_hint(k == 0, n == 0)
             k += 1
             if k > max_attempts:
                 raise RuntimeError("step did not finish within %d attempts" % max_attempts)
@@ -263,6 +284,7 @@ class BatchEngine:
             k += 1
             if self.get("overflow").any():
                 self._raise_overflow()
+            self._update_igr_hint(True, True)
             done = self.get("nsub") > before
             a = self.arr["active"]
             a[...] = self.be.from_numpy(np.where(done, 0, self.get("active")).astype(np.int32))

@@ -45,7 +45,7 @@ FIELDS = [
     ("igr_items_cap", "i"), ("igr_qcap", "i"), ("igr_rounds", "i"),
     ("igr_list", "pi"), ("igr_hdr", "pi"), ("igr_cface", "pi"), ("igr_cstate", "pi"), ("igr_cbuf", "pd"),
     ("igr_qpts", "pd"), ("igr_qlat", "pi"), ("igr_qtag", "pi"), ("igr_qsdf", "pd"), ("igr_qgrad", "pd"), ("igr_qn", "pi"),
-    ("igr_ev", "ev"),
+    ("igr_hint", "ev"), ("igr_ev", "ev"),
 ]
 IGR_HDR, IGR_ROUNDS = 16, 42
 

@@ -216,6 +216,10 @@ typedef struct DssWorld {
     double *igr_qsdf;        /* [4][igr_qcap] network outputs */
     double *igr_qgrad;       /* [2][igr_qcap][3] d phi / d xyz of the gradient lists */
     int *igr_qn;             /* [2 (DSS_IGR_ROUNDS + 2)] list lengths: value and gradient list of every round */
+    const int *igr_hint;     /* optional, HOST memory, [2 (DSS_IGR_ROUNDS + 2)]: what the previous detection found -- [0] the number of
+                                neural work items, [2 r + l] the length of list l in round r (r >= 1; the caller copies igr_qn back
+                                and writes the item count, n_pairs[6], over entry 0).  Sizes the grids only: every launch strides over
+                                whatever the device-side lengths turn out to be.  NULL = grids that fill the chip. */
     void **igr_ev;           /* optional hipEvent_t [4 (DSS_IGR_ROUNDS + 1)] in HOST memory: (start, stop) around the value-list and the
                                 gradient-list evaluation of every round (bench roofline); NULL in production */
 } DssWorld;
