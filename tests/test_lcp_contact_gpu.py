@@ -95,4 +95,44 @@ def test_full_batch_properties_config3_size():
         rz = G @ x[s] + sl - h - F @ z
         worst = max(worst, np.abs(rx).max(), np.abs(rz).max(), np.abs(A @ x[s] - b).max())
         checked += 1
-    assert checked > 10 and worst < 1.0, (checked, worst)
+    print("worst residual over", checked, "converged systems:", worst)
+    # random contact sets: after the engine's 10 iterations the primal residual of the converged ones is at the 1e-3 level
+    # (measured 1.9e-3 over 142 systems); the physical operands of the benchmark scenes are held tighter below
+    assert checked > 100 and worst < 5e-3, (checked, worst)
+
+
+def test_lcp_conditions_hold_on_the_benchmark_scenes():
+    """The LCPs of BASELINE configs[2] as the stepper assembles them (1024 different box stacks, 80-110 contacts each, the
+    operands of the last attempt): every scene converges (status 0), and the solution satisfies the conditions the
+    reference's solver iterates on (batch.py:117-131) -- stationarity and the equality rows to round-off (every Newton step
+    solves them exactly once a full step was taken), primal feasibility and complementarity to the interior point method's
+    accuracy after its 10 iterations (engines.py:25)."""
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.engine import BatchEngine
+    E = BatchEngine(scenes.box_stack(1024, nbox=7, seed=4242), maxc=128, max_cand=1024, max_pc=48, max_sub=0, strict_no_pen=False)
+    for _ in range(2):
+        E.step()
+    st, nc = E.get("lcp_status"), E.get("nc")
+    assert (st == 0).all(), np.unique(st)
+    P = dict(Mblk=E.get("Mblk"), pvec=E.get("pvec"), A=E.get("Je"), bvec=np.zeros((E.B, E.neq)), cop=E.get("cop"),
+             cbody=E.get("cop_body"), nc=E.get("lcp_iters") * 0 + E.get("nc"), nb=E.nb, neq=E.neq, maxc=E.maxc, fd=E.fd)
+    x, lam, slack, nu = E.get("x"), E.get("lam"), E.get("slack"), E.get("nu")
+    # the operands in the engine's arrays are those of the LAST attempt, whose contact count is the one before the
+    # detection that followed it: read it off the multipliers (rows beyond it are untouched zeros)
+    worst = dict(rx=0.0, ry=0.0, rz=0.0, comp=0.0)
+    ncs = []
+    for s in range(0, 1024, 37):
+        n_used = int((np.abs(lam[s][0]) > 0).sum())
+        P["nc"][s] = n_used
+        ncs.append(n_used)
+        fd = P["fd"]
+        Q, p, G, h, A, b, F = S.expand_dense(P, s)
+        z, sl = S.struct_vec(lam[s], n_used, fd), S.struct_vec(slack[s], n_used, fd)
+        assert (z > 0).all() and (sl > 0).all()
+        scale = max(1.0, np.abs(p).max())
+        worst["rx"] = max(worst["rx"], np.abs(Q @ x[s] + G.T @ z + A.T @ nu[s] + p).max() / scale)
+        worst["ry"] = max(worst["ry"], np.abs(A @ x[s] - b).max())
+        worst["rz"] = max(worst["rz"], np.abs(G @ x[s] + sl - h - F @ z).max())
+        worst["comp"] = max(worst["comp"], float(sl @ z) / len(z))
+    assert min(ncs) >= 60 and max(ncs) <= 128, (min(ncs), max(ncs))
+    assert worst["rx"] < 1e-9 and worst["ry"] < 1e-10 and worst["rz"] < 1e-6 and worst["comp"] < 1e-6, worst

@@ -197,3 +197,21 @@ def test_escape_from_endless_halving_keeps_the_penetrating_contacts_like_the_ref
             a = np.sort(tg[j, 0][3:6, :n].T, axis=0); b = np.sort(g["traj_geom"][j - 1][:n, 3:6], axis=0)
             assert np.abs(a - b).max() < 1e-7
     R.check_gradients(E, g, tol=1e-5)
+
+
+def test_config3_scene_at_full_batch_replicas_are_bit_identical_and_match_the_reference():
+    """BASELINE configs[2]'s own scene (floor + 7 stacked boxes, 123-128 contacts) replicated B = 1024 times: every replica
+    bit-identical to the first (poses, velocities, contact counts, gradients), the first within the single-scene
+    tolerances of the reference golden.  The whole batch machinery (work lists of the persistent narrow phase over 14 k
+    items, one LCP wavefront per scene, the reverse sweep's per-scene scratch) at the size the metric is quoted on."""
+    g, E = make("rollout_stack7", 1024, max_sub=16, maxc=128)
+    R.rollout_and_sweep(E, 3)
+    assert int(E.get("overflow").max()) == 0 and (E.get("nsub") == len(g["traj_t"])).all()
+    k = len(g["traj_t"]) - 1
+    pose, vel, nc = E.get("pose"), E.get("vel"), E.get("nc")
+    assert np.abs(pose[0] - g["traj_p"][k]).max() < 1e-7 and np.abs(vel[0] - g["traj_v"][k]).max() < 1e-6
+    assert (pose == pose[:1]).all() and (vel == vel[:1]).all() and (nc == nc[0]).all()
+    gp, gm = E.be.to_numpy(E.adj["g_prm"]), E.be.to_numpy(E.adj["g_mass"])
+    assert np.isfinite(gp).all() and (gp == gp[:1]).all() and (gm == gm[:1]).all()
+    for s in (0, 511, 1023):
+        R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]), tol=1e-5)
