@@ -538,7 +538,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         double tri[3][3], n[3], p1[3], p2[3], pen;
         for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = m_verts[(size_t)(A.voff + fv[v]) * 3 + i];
         const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
-        contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen);
+        int stable = -1;
+        contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen, &stable);
+        if (!stable) kface[k] |= DSS_FACE_NORMAL1;     // which body's normal it is travels with the face id
         for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; CB(i, k) = p2[i]; }   // pqr (fields 0-8) is dead by now
         CB(24, k) = pen;
         if (!(pen <= W.tol)) bad = 1;
@@ -547,7 +549,8 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
         // attempts that will be accepted all the same (decide_kernel: strict_no_penetration=False, dt < dt / 2^10) keep this
         // direction's contacts as they are
-        if (!W.strict_no_pen && W.dt_try[sc] < W.dt / 1024.0) { G::sync(); emit_unfiltered<G>(W, sc, dp, ncon, over, kface, cb, MC); }
+        // (dt_try = 0: detection outside a step, World.__init__)
+        if (!W.strict_no_pen && W.dt_try[sc] > 0.0 && W.dt_try[sc] < W.dt / 1024.0) { G::sync(); emit_unfiltered<G>(W, sc, dp, ncon, over, kface, cb, MC); }
         return 0;
     }
 

@@ -573,6 +573,7 @@ __device__ void advance(const DssWorld &W, ScratchT<G> &S, int it, int round, in
                     lap[body] = acc;
                 }
                 const bool stable = fabs(lap[1]) < fabs(lap[0]);
+                if (!stable) kface[j] |= DSS_FACE_NORMAL1;
                 double n[3], t[3], p1[3], p2[3];
                 if (stable) quat_apply(Bd.g.q, n2, n);
                 else { quat_apply(A.g.q, n1, t); for (int i = 0; i < 3; ++i) n[i] = -t[i]; }

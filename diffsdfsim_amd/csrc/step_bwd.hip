@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W_arg, DssAdj
             double pt[3];
             if (side == 0) {
                 const int mesh = W.mesh_id[(size_t)sc * nb + b1];
-                const int *fv = W.faces + (size_t)(W.mesh_foff[mesh] + v.face_n[c]) * 3;
+                const int *fv = W.faces + (size_t)(W.mesh_foff[mesh] + DSS_FACE_ID(v.face_n[c])) * 3;
                 pt[0] = pt[1] = pt[2] = 0.0;
                 for (int q = 0; q < 3; ++q) {
                     const double *vp = W.verts + (size_t)(W.mesh_voff[mesh] + fv[q]) * 3, w = v.abc_n[(size_t)q * MX + c];
@@ -283,14 +283,14 @@ __global__ void __launch_bounds__(64) bwd_igr_prep_kernel(DssWorld W_arg, DssAdj
 }
 
 // records of contact c: lin[0 .. 2 IGR_LIN) body 1 (queries at the triangle point and after the Newton step), lin[2 IGR_LIN ..)
-// body 2; `stable` = which normal the forward pass picked, read off the taped normal
+// body 2; `stable` = which normal the forward pass picked (the flag in the contact's face word)
 __device__ void igr_records(const DssWorld &W, const DssAdjoint &A, int sc, const SlotView &v, int c, int i1, int i2, double *lin,
                             int &stable)
 {
     const int nb = W.nb, MX = W.maxc, b1 = v.body_n[c], b2 = v.body_n[MX + c];
     const size_t cap = (size_t)W.B * 2 * MX;
     const double *sdfX = A.igr_bw_sdf, *gX = A.igr_bw_grad, *gL = A.igr_bw_grad + cap * 3;
-    const double *P1 = v.pose_n + 7 * b1, *P2 = v.pose_n + 7 * b2;
+    const double *P1 = v.pose_n + 7 * b1;
     for (int i = 0; i < 3 * IGR_LIN; ++i) lin[i] = 0.0;
     auto fill = [&](double *r, int idx, double scale) {
         if (idx < 0) { r[0] = scale; return; }      // outside the query cube: phi = scale, everything else zero
@@ -301,23 +301,10 @@ __device__ void igr_records(const DssWorld &W, const DssAdjoint &A, int sc, cons
         normalize(raw, r + 6);
     };
     if (i1 != -1) fill(lin, i1, W.shape_aux[(size_t)sc * nb + b1]);
-    double n2[3];
-    if (i2 != -1) {
-        fill(lin + 2 * IGR_LIN, i2, W.shape_aux[(size_t)sc * nb + b2]);
-        for (int i = 0; i < 3; ++i) n2[i] = lin[2 * IGR_LIN + 6 + i];
-    } else {
-        Shape<double> s2;
-        make_shape(s2, W.shape_type[(size_t)sc * nb + b2], W.shape_prm + ((size_t)sc * nb + b2) * 3, W.shape_aux[(size_t)sc * nb + b2]);
-        double rel[3], cp2[3], d2;
-        for (int i = 0; i < 3; ++i) rel[i] = (v.geom_n[(size_t)(3 + i) * MX + c] + P1[4 + i]) - P2[4 + i];
-        quat_apply_inv(P2, rel, cp2);
-        query_sdf(s2, cp2, d2, n2, true);
-    }
+    if (i2 != -1) fill(lin + 2 * IGR_LIN, i2, W.shape_aux[(size_t)sc * nb + b2]);
+    // which body's normal the contact carries was decided in the forward pass and travels with the face id
     const double nt[3] = {v.geom_n[c], v.geom_n[(size_t)MX + c], v.geom_n[(size_t)2 * MX + c]};
-    double n2w[3], dd = 0.0;
-    quat_apply(P2, n2, n2w);
-    for (int i = 0; i < 3; ++i) dd += (n2w[i] - nt[i]) * (n2w[i] - nt[i]);
-    stable = dd < 1e-18;
+    stable = (v.face_n[c] & DSS_FACE_NORMAL1) ? 0 : 1;
     if (i1 != -1 && !stable) {       // the normal used is body 1's after the Newton step: n = -R1 n1'  ->  n1' = -R1^T n
         double t[3];
         quat_apply_inv(P1, nt, t);
@@ -491,7 +478,9 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
             }
         }
 #endif
-        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], v.face_n[c], abc, gb, out, A.g_verts, l1, l2, st);
+        // the forward pass's normal choice travels with the face id: the Laplacian probes are not repeated
+        if (st < 0) st = (v.face_n[c] & DSS_FACE_NORMAL1) ? 0 : 1;
+        contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], DSS_FACE_ID(v.face_n[c]), abc, gb, out, A.g_verts, l1, l2, st);
         for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
     }
     __syncthreads();

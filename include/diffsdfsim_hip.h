@@ -160,7 +160,9 @@ typedef struct DssWorld {
     /* current contacts (geometry at the current pose) [B][...] */
     int *nc;                 /* [B] */
     int *c_body;             /* [B][2][maxc] */
-    int *c_face;             /* [B][maxc] face id in the mesh of body 1 */
+    int *c_face;             /* [B][maxc] face id in the mesh of body 1 (DSS_FACE_ID), | DSS_FACE_NORMAL1 if the contact carries body
+                                1's normal (the `stable_mask` decision of contacts.py:184-202, kept for the reverse sweep and for
+                                parity tests); stored as -1 - (that word) for a contact without geometry adjoint (world.py:345-347) */
     double *c_abc;           /* [B][3][maxc] barycentrics */
     double *c_geom;          /* [B][10][maxc] n(3) p1(3) p2(3) pen */
     /* contacts detected by the current attempt; committed on accept */
@@ -224,6 +226,8 @@ typedef struct DssWorld {
                                 gradient-list evaluation of every round (bench roofline); NULL in production */
 } DssWorld;
 
+#define DSS_FACE_NORMAL1 (1 << 30)        /* flag in a contact's face word: normal = -R1 n1 (body 1's), not R2 n2 */
+#define DSS_FACE_ID(w) ((w) & (DSS_FACE_NORMAL1 - 1))
 #define DSS_N_ACTIVE_OVERFLOW (1 << 30)   /* set in n_active[0] once any scene's overflow word is non-zero */
 #define DSS_CAND_FIELDS 28  /* pqr(9) x(3) abc(3) | abc_k(3) n(3) p1(3) pen spare(3) */
 #define DSS_CSCR_ROWS 56

@@ -18,6 +18,9 @@ from oracle import refshim  # noqa: E402
 
 refshim.install()
 from oracle.gen import scenes  # noqa: E402
+from oracle.gen import contact_record  # noqa: E402
+
+contact_record.install()
 from sdf_physics.physics3d.world import World3D  # noqa: E402
 from sdf_physics.physics3d.bodies import SDFBowl, SDFBox, SDFBoxRounded, SDFBrick, SDFCylinder, SDFSphere  # noqa: E402
 
@@ -71,6 +74,12 @@ def describe(bodies, g=10.0, store_mesh=True):
     return d
 
 
+def stable_arrays(trajectory):
+    st = np.stack([contact_record.lookup(e[3], MAXC)[0] for e in trajectory])
+    lap = np.stack([contact_record.lookup(e[3], MAXC)[1] for e in trajectory])
+    return st, lap
+
+
 def branch_b_grads(make, nsteps, toc, jitter=1e-13, **world_kw):
     """The reference's gradient is bimodal on flat-on-flat contacts: `stable_mask = |lap2| < |lap1|`
     (contacts.py:198) compares two rounding-noise Laplacians, so which body's normal carries the gradient
@@ -79,11 +88,13 @@ def branch_b_grads(make, nsteps, toc, jitter=1e-13, **world_kw):
     with torch.no_grad():
         bodies[-1].v[3] += jitter
     w = World3D(bodies, joints, time_of_contact_diff=toc, **world_kw)
+    init_stable = contact_record.lookup(w.contacts, MAXC)[0]
     for _ in range(nsteps):
         w.step(fixed_dt=True)
     loss = sum((b.pos ** 2).sum() for b in bodies)
-    return [np.zeros_like(p.detach().numpy()) if g is None else g.numpy()
-            for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True))]
+    grads = [np.zeros_like(p.detach().numpy()) if g is None else g.numpy()
+             for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True))]
+    return grads, stable_arrays(w.trajectory)[0], init_stable
 
 
 def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
@@ -95,6 +106,7 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
     d["strict_no_pen"] = int(w.strict_no_pen)
     b0, g0 = contacts_arrays(w.contacts)
     d["init_body"], d["init_geom"] = b0, g0
+    d["init_stable"], d["init_lap"] = contact_record.lookup(w.contacts, MAXC)
     for _ in range(nsteps):
         w.step(fixed_dt=True)
     T = len(w.trajectory)
@@ -108,6 +120,9 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
         b, g = contacts_arrays(e[3])
         cb[k, :len(b)] = b; cg[k, :len(b)] = g
     d["traj_nc"], d["traj_body"], d["traj_geom"] = nc, cb, cg
+    # which body's normal every contact carries (1 = body 2's, 0 = body 1's, -1 = not recorded) and the two Laplacian
+    # magnitudes the choice compared (contacts.py:184-198)
+    d["traj_stable"], d["traj_lap"] = stable_arrays(w.trajectory)
     d["t_final"] = float(w.t)
     loss = sum((b.pos ** 2).sum() for b in bodies)
     if params:
@@ -115,8 +130,10 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
         for i, (p, g) in enumerate(zip(params, grads)):
             d["param_%d" % i] = p.detach().numpy()
             d["grad_%d" % i] = np.zeros_like(p.detach().numpy()) if g is None else g.numpy()
-        for i, gb in enumerate(branch_b_grads(make, nsteps, toc, **world_kw)):
+        gbs, stB, d["init_stableB"] = branch_b_grads(make, nsteps, toc, **world_kw)
+        for i, gb in enumerate(gbs):
             d["gradB_%d" % i] = gb
+        d["traj_stableB"] = stB if stB.shape == d["traj_stable"].shape else np.full_like(d["traj_stable"], -1)
     d["loss"] = float(loss)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print(name, "substeps", T, "for", nsteps, "steps; nc range", nc.min(), nc.max(), "loss", float(loss),

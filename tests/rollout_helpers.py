@@ -84,19 +84,27 @@ def param_grads(E, g, s=0):
     return out
 
 
-def check_gradients(E, g, tol=1e-5, s=0):
+def check_gradients(E, g, tol=1e-5, s=0, branch_tol=1e-5):
     """Reference gradients are bimodal on flat-on-flat contacts (see oracle/gen/gen_rollout_golden.py:
-    `stable_mask` compares two rounding-noise Laplacians); both branches are in the golden and the kernel
-    must reproduce one of them."""
+    `stable_mask` compares two rounding-noise Laplacians); both branches are in the golden.  Where the golden records the
+    reference's choice per contact, the build's choices are compared with it (check_branches_and_pick_reference): the same
+    branch is REQUIRED wherever the margin exceeds noise, and if the build took exactly the choices of one of the two
+    recorded runs its gradient must equal that run's to `branch_tol` (north_star: 1e-5).  Otherwise (choices mixed between
+    the two runs on coin-flip contacts) it must be within `tol` of the nearer one."""
     got = param_grads(E, g, s)
-    errs = []
-    for key in ("grad_%d", "gradB_%d"):
+    errs = {}
+    for tag, key in (("A", "grad_%d"), ("B", "gradB_%d")):
         e = 0.0
         for i, gi in enumerate(got):
             want = g[key % i]
             e = max(e, np.abs(gi - want).max() / max(np.abs(want).max(), 1e-300))
-        errs.append(e)
-    assert min(errs) < tol, (errs, got)
+        errs[tag] = e
+    which = check_branches_and_pick_reference(E, g, s) if "traj_stable" in g else None
+    if which is not None:
+        assert errs[which] < branch_tol, (which, errs, got)
+    else:
+        assert min(errs.values()) < tol, (errs, got)
+    return which, errs
 
 
 def rollout_and_sweep(E, nsteps):
@@ -111,3 +119,65 @@ def rollout_and_sweep(E, nsteps):
     E.backward_sweep(int(E.get("nsub").max()) + 1)
 
 
+
+
+def _quat_to_mat(q):
+    r, i, j, k = q
+    s = 2.0 / (q * q).sum()
+    return np.array([[1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r)],
+                     [s * (i * j + k * r), 1 - s * (i * i + k * k), s * (j * k - i * r)],
+                     [s * (i * k - j * r), s * (j * k + i * r), 1 - s * (i * i + j * j)]])
+
+
+FACE_NORMAL1 = 1 << 30      # DSS_FACE_NORMAL1 (include/diffsdfsim_hip.h): the contact carries body 1's normal
+
+
+def contact_branches(face, n):
+    """Which body's normal each of the n contacts carries (1 = body 2's, the reference's `stable_mask`; 0 = body 1's): the flag
+    the narrow phase stores in the contact's face word (where the normals of the two bodies coincide -- flat on flat -- the
+    choice cannot be read off the normal itself, yet it decides which body's SDF the gradient flows through)."""
+    w = np.where(face[:n] < 0, -1 - face[:n], face[:n])
+    return ((w & FACE_NORMAL1) == 0).astype(np.int8)
+
+
+def check_branches_and_pick_reference(E, g, s=0, margin=1e-9):
+    """Compare the normal choice of every contact of every recorded sub-step with the reference's (`traj_stable`, recorded by
+    oracle/gen/contact_record.py).  Where the two Laplacians the reference compared differ by more than rounding noise the
+    build MUST take the same branch (asserted).  Returns 'A' / 'B' if the build's choices equal those of the reference's first
+    / second (jittered) run at EVERY contact, coin flips included -- its gradient is then comparable to that run's to 1e-5 --
+    else None."""
+    tp, tnc, tb, tg, tf = E.get("tp_pose"), E.get("tp_nc"), E.get("tp_body"), E.get("tp_geom"), E.get("tp_face")
+    k = len(g["traj_t"]) - 1
+    same = {"A": True, "B": "traj_stableB" in g}
+    steps = [(j, tf[j, s], tb[j, s], tg[j, s], int(tnc[j, s])) for j in range(0, k + 1)]      # slot 0: the contacts found at construction
+    steps.append((k + 1, E.get("c_face")[s], E.get("c_body")[s], E.get("c_geom")[s], int(E.get("nc")[s])))
+    for j, face, body, geom, n in steps:
+        if j == 0:
+            if "init_stable" not in g:
+                return None
+            ref_n, gb, gg = len(g["init_body"]), g["init_body"], g["init_geom"]
+            ref_st, ref_lap, ref_stB = g["init_stable"], g["init_lap"], g.get("init_stableB")
+        else:
+            ref_n, gb, gg = int(g["traj_nc"][j - 1]), g["traj_body"][j - 1], g["traj_geom"][j - 1]
+            ref_st, ref_lap, ref_stB = g["traj_stable"][j - 1], g["traj_lap"][j - 1], (g["traj_stableB"][j - 1] if "traj_stableB" in g else None)
+        if n == 0 or n != ref_n:
+            continue
+        mine = contact_branches(face, n)
+        # pair the build's contacts with the reference's by contact point (the order inside a body pair may differ)
+        gb, gg = gb[:n], gg[:n]
+        for c in range(n):
+            cand = [r for r in range(n) if tuple(gb[r]) == (int(body[0, c]), int(body[1, c])) and np.abs(gg[r, 3:6] - geom[3:6, c]).max() < 1e-6]
+            if len(cand) != 1:
+                continue
+            r = cand[0]
+            ref, lap = int(ref_st[r]), ref_lap[r]
+            if ref < 0:
+                same["A"] = same["B"] = False     # an unrecorded choice: the run cannot be identified
+                continue
+            if abs(lap[1] - lap[0]) > margin * max(1.0, lap.max()):
+                assert mine[c] == ref, ("normal taken from the other body than in the reference", j, c, lap)
+            same["A"] &= mine[c] == ref
+            if same["B"]:
+                refb = int(ref_stB[r]) if ref_stB is not None else -1
+                same["B"] &= refb >= 0 and mine[c] == refb
+    return "A" if same["A"] else ("B" if same["B"] else None)
