@@ -27,11 +27,13 @@ __global__ void __launch_bounds__(64) begin_kernel(DssWorld W)
 {
     const int sc = blockIdx.x * 64 + threadIdx.x;
     if (sc >= W.B) return;
+    if (W.step_mask && !W.step_mask[sc]) { W.active[sc] = 0; return; }      // this scene sits the step out
     const double t = W.t[sc];
     W.t_end[sc] = t + W.dt;          // end_t = self.t + self.dt            (world.py:129)
     W.dt_try[sc] = (t + W.dt) - t;   // dt = end_t - self.t                 (world.py:131)
     W.active[sc] = 1;
-    if (sc == 0) W.n_active[0] = W.B;
+    if (W.had_contacts) W.had_contacts[sc] = 0;
+    atomicAdd(W.n_active, 1);
 }
 
 __global__ void __launch_bounds__(64) assemble_kernel(DssWorld W)
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
         }
         if (lane == 0) {
             W.nc[sc] = nc_new;
+            if (W.had_contacts && nc_new > 0) W.had_contacts[sc] = 1;      // `if self.contacts: had_contacts = True` (world.py:133-138)
             W.toc[sc] = toc;
             if (W.toc_diff && toc && !escaped) W.last_dt[sc] = W.dt_use[sc];   // world.py:341
             W.nsub[sc] = slot + 1;
@@ -237,6 +240,7 @@ int dss_step_begin(const DssWorld *W, void *stream)
 {
     int rc = check_world(W);
     if (rc) return rc;
+    (void)hipMemsetAsync(W->n_active, 0, sizeof(int), (hipStream_t)stream);
     hipLaunchKernelGGL(begin_kernel, dim3((W->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *W);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }

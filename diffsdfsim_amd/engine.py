@@ -243,11 +243,19 @@ class BatchEngine:
         return self.be.to_numpy(self.arr[name])
 
     # -- stepping --------------------------------------------------------------------------------
-    def step(self, max_attempts=4096):
-        """One outer step of length dt for every scene (World.step(fixed_dt=True))."""
+    def step(self, max_attempts=4096, mask=None):
+        """One outer step of length dt for every scene (World.step(fixed_dt=True)); with `mask` ([B] of 0/1) only for the
+        scenes it selects -- the others keep their state and time (a batch whose scenes are at different times)."""
         L, W = self.be.lib, self.W
+        if mask is not None:
+            if "step_mask" not in self.arr:
+                self.arr["step_mask"] = self.be.zeros((self.B,), np.int32)
+            self.arr["step_mask"][...] = self.be.from_numpy(np.asarray(mask, np.int32))
+            W.step_mask = self.be.ptr(self.arr["step_mask"])
+        else:
+            W.step_mask = None
         self._check(L.dss_step_begin(ctypes.byref(W), self.be.stream()), "dss_step_begin")
-        n = self.B
+        n = self.B if mask is None else int(np.asarray(mask, np.int32).sum())
         k = 0
         while n > 0:
             self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
@@ -275,6 +283,7 @@ class BatchEngine:
         """World.step(fixed_dt=False): a single step_dt -- attempts until the first accepted sub-step
         (world.py:136-139).  Scenes of a batch that accept early simply wait (exact for B = 1)."""
         L, W = self.be.lib, self.W
+        W.step_mask = None
         self._check(L.dss_step_begin(ctypes.byref(W), self.be.stream()), "dss_step_begin")
         before = self.get("nsub").copy()
         k = 0

@@ -1,28 +1,38 @@
-"""Batched experiment drivers: the trajectory-fitting loop of
-`experiments/trajectory_fitting/optim_sphere.py:114-177` (make a world from the current parameter estimate, roll it out
-with fixed outer steps, compare with a target trajectory, step the parameter along the gradient) for a whole batch of
-independent scenes at once, without sacred / pyrender.
+"""Batched experiment drivers: the optimisation loops of the reference's `experiments/`, for a whole
+batch of independent scenes at once, without sacred / tensorboard / pyrender.
 
-    rollout(world, steps)                 -> poses [T,B,nb,7], velocities [T,B,nb,6]   (autograd-connected)
-    trajectory_loss(traj, traj_target)    -> [B]  mean over time of |pos - pos_target|^2 of the last body (optim_sphere.py:114-160)
-    sphere_world(radii, ...)              -> BatchWorld3D of config 2's scene with the given per-scene radii; shape and
-                                             inertia are functions of `radii`, so d loss / d radii flows
-    fit_sphere_radius(...)                -> the optimisation loop; returns the history
-    export_trajectory(path, ...)          -> .npz of (T, B, nb, 13) trajectories (pyrender-free export)
+trajectory fitting  (experiments/trajectory_fitting/optim_sphere.py)
+    bounce_world(radii, ...)                      floor + wall + sphere thrown at the wall (:77-111), one scene per radius
+    run_world_fixed_dt(world, run_time, detach_2nd_bounce)   fixed outer steps until every scene has reached run_time; with
+                                                  detach_2nd_bounce the second step in a row that ends in contact is undone
+                                                  and redone with poses and velocities cut from the graph (:163-177), per scene
+    trajectory_loss(traj, traj_target)            mean over a scene's entries of |pos - pos_target|^2 at the nearest target time (:114-160)
+    chamfer(a, b)                                 symmetric mean squared nearest-neighbour distance (pytorch3d.loss.chamfer_distance, :244)
+    fit_sphere_radius(...)                        the gradient-descent loop (:210-270) for B (target, start) pairs; radius_error_table()
+                                                  prints min / mean / max |r - r*| like RESULTS.md:14-47
+inertia fitting  (experiments/inertia_fitting/optim_shapespace.py)
+    spin_world(latents, torque_dirs, net)         one neural-SDF body per scene, translation locked (X/Y/Z constraints), torque for
+                                                  t < 0.3 (:71-92); inertia from the body's level-set mesh, differentiable w.r.t. the latent
+    fit_inertia_latent(...)                       the loop of :136-250: loss = |v_T - v_T*|^2 + reg |latent|^2
 
-    python -m diffsdfsim_amd.experiments --scenes 64 --steps 30 --iters 15
+    python -m diffsdfsim_amd.experiments sphere --scenes 64 --iters 100
+    python -m diffsdfsim_amd.experiments inertia --scenes 8 --iters 10
 """
 import argparse
+import math
 
 import numpy as np
 import torch
 
-from . import meshes, scenes
+from . import mass_properties, meshes, meshsdf, scenes
 from . import world_abi as abi
 from .physics3d import BatchWorld3D
+from .physics3d.utils import Defaults3D
 
 
+# ---- rollouts ------------------------------------------------------------------------------------------------------------
 def rollout(world, steps):
+    """`steps` fixed outer steps of every scene -> poses [T,B,nb,7], velocities [T,B,nb,6] (autograd-connected)."""
     P, V = [], []
     for _ in range(steps):
         world.step()
@@ -31,65 +41,217 @@ def rollout(world, steps):
     return torch.stack(P), torch.stack(V)
 
 
-def trajectory_loss(traj_pose, target_pose, body=-1):
-    """Fixed outer steps put both trajectories on the same time grid, so the reference's nearest-time search
-    (optim_sphere.py:121-139) is the identity pairing."""
-    d = traj_pose[:, :, body, 4:] - target_pose[:, :, body, 4:].to(traj_pose)
-    return (d * d).sum(dim=2).mean(dim=0)
+def run_world_fixed_dt(world, run_time, detach_2nd_bounce=False, max_steps=10000):
+    """`run_world_fixed_dt` (optim_sphere.py:163-177) per scene of a batch.  Returns the trajectory as a dict of
+    t [K,B], pose [K,B,nb,7], vel [K,B,nb,6], valid [K,B]: entry k of scene s is valid if the scene took outer step k and the
+    step was not undone (an undone step is dropped from the reference's trajectory list, world.py:106-116)."""
+    B, dev = world.B, world.device
+    num_contact = np.zeros(B, np.int64)
+    T, P, V, OK = [], [], [], []
+    for _ in range(max_steps):
+        t = world.t
+        mask = t < run_time
+        if not mask.any():
+            break
+        had = np.asarray(world.step(mask=mask)) & mask
+        redo = np.zeros(B, bool)
+        if detach_2nd_bounce:
+            num_contact += had
+            redo = had & (num_contact > 1)
+            if redo.any():
+                world.undo_step(redo)
+                world.detach_state(redo)
+                num_contact[redo] = 0
+        T.append(torch.as_tensor(world.t.copy(), device=dev)); P.append(world.pose); V.append(world.vel)
+        OK.append(torch.as_tensor(mask & ~redo, device=dev))
+    return dict(t=torch.stack(T), pose=torch.stack(P), vel=torch.stack(V), valid=torch.stack(OK))
 
 
-def sphere_world(radii, y0, vx, floor_dims=(20.0, 1.0, 20.0), mu=0.25, rest=0.5, g=10.0, steps=64, toc=True, device=None):
-    """Config 2's scene for explicit per-scene radius / drop height / lateral speed."""
-    rad = np.asarray(radii.detach().cpu() if torch.is_tensor(radii) else radii, np.float64)
+def trajectory_loss(traj, target, body=-1):
+    """optim_sphere.py:114-160: every entry of a scene's trajectory is compared with the target entry nearest in time (position
+    of the last body; the sum over the scene's entries divided by their number).  -> [B]"""
+    tw, tt = traj["t"], target["t"].to(traj["t"])
+    diff = (tw[:, None, :] - tt[None, :, :]).abs()                                                             # [Kw, Kt, B]
+    diff = torch.where(target["valid"].to(tw.device)[None, :, :], diff, torch.full_like(diff, float("inf")))
+    j = diff.argmin(dim=1)                                                                                      # [Kw, B]
+    pos_t = target["pose"][:, :, body, 4:].to(traj["pose"])
+    near = torch.gather(pos_t, 0, j[:, :, None].expand(-1, -1, 3))
+    d = traj["pose"][:, :, body, 4:] - near
+    w = traj["valid"].to(d.dtype)
+    return ((d * d).sum(dim=2) * w).sum(dim=0) / w.sum(dim=0).clamp_min(1.0)
+
+
+def chamfer(a, b):
+    """pytorch3d.loss.chamfer_distance of two point sets a [Na,3], b [Nb,3] (defaults: squared distances, mean over the points of
+    each set, the two directions summed)."""
+    d = torch.cdist(a, b) ** 2
+    return d.min(dim=1).values.mean() + d.min(dim=0).values.mean()
+
+
+# ---- trajectory fitting: a sphere thrown at a wall (optim_sphere.py) --------------------------------------------------------
+def bounce_world(radii, use_toc_diff=True, use_friction=True, use_wall=True, use_floor=True, use_gravity=True,
+                 sphere_pos=(0.0, 5.0, 0.0), sphere_vel=(5.0, 0.0, 0.0), run_time=1.5, dt=Defaults3D.DT, device=None):
+    """optim_sphere.py:77-111 for one scene per radius: floor 20 x 1 x 20, wall [5,5,0] 1 x 10 x 10 (both pinned, no contact
+    with each other), a sphere of the scene's radius at (0,5,0) thrown with (5,0,0); restitution 0.5, friction 0.25 (0 without).
+    Analytic meshes and inertias (the reference's custom_mesh / custom_inertia); shape and inertia are functions of `radii`."""
+    rad = np.asarray(radii.detach().cpu() if torch.is_tensor(radii) else radii, np.float64).reshape(-1)
     B = len(rad)
-    spec, cache = scenes._base(B, 2), {}
-    scenes._floor(spec, cache, floor_dims, mu, rest)
+    fixed = [n for n, on in (("floor", use_floor), ("wall", use_wall)) if on]
+    nb = len(fixed) + 1
+    mu = 0.25 if use_friction else 0.0
+    spec, cache = scenes._base(B, nb), {}
+    spec["Je"] = np.zeros((B, 6 * len(fixed), 6 * nb))
+    nocon = np.zeros((nb, nb), np.uint8)
+    for k, name in enumerate(fixed):
+        dims, pos = ((20.0, 1.0, 20.0), (0.0, -0.5, 0.0)) if name == "floor" else ((1.0, 10.0, 10.0), (5.0, 5.0, 0.0))
+
+        def make(dims=dims):
+            v, f, tie = meshes.box_mesh(np.asarray(dims))
+            return v, f, 0.5 * tie
+        spec["mesh_id"][:, k] = scenes._add_mesh(spec, cache, ("box",) + tuple(dims), make)
+        spec["pose"][:, k, 4:] = pos
+        spec["shape_prm"][:, k] = dims
+        spec["inertia"][:, k] = scenes.box_inertia(1.0, np.asarray(dims))
+        spec["fric"][:, k] = mu
+        spec["restitution"][:, k] = Defaults3D.RESTITUTION
+        spec["Je"][:, 6 * k:6 * k + 6, 6 * k:6 * k + 6] = np.eye(6)
+    if len(fixed) == 2:
+        nocon[0, 1] = nocon[1, 0] = 1
+    spec["no_contact"] = nocon
     uv, uf = meshes.icosphere(4)
+    s_ = nb - 1
     for s in range(B):
-        spec["mesh_id"][s, 1] = scenes._add_mesh(spec, cache, ("sphere", float(rad[s])), lambda r=float(rad[s]): (uv * r, uf, uv.copy()))
-        spec["shape_type"][s, 1] = abi.SHAPE_SPHERE
-        spec["shape_prm"][s, 1, 0] = rad[s]
-        spec["pose"][s, 1, 4:] = (0.0, y0[s], 0.0)
-        spec["vel"][s, 1, 3] = vx[s]
-        spec["inertia"][s, 1] = 0.4 * rad[s] ** 2 * np.eye(3)
-        spec["fric"][s, 1] = mu
-        spec["restitution"][s, 1] = rest
-        spec["fext"][s, 1, 4] = -g
+        spec["mesh_id"][s, s_] = scenes._add_mesh(spec, cache, ("sphere", float(rad[s])), lambda r=float(rad[s]): (uv * r, uf, uv.copy()))
+    spec["shape_type"][:, s_] = abi.SHAPE_SPHERE
+    spec["shape_prm"][:, s_, 0] = rad
+    spec["pose"][:, s_, 4:] = sphere_pos
+    spec["vel"][:, s_, 3:] = sphere_vel
+    spec["inertia"][:, s_] = 0.4 * rad[:, None, None] ** 2 * np.eye(3)
+    spec["fric"][:, s_] = mu
+    spec["restitution"][:, s_] = Defaults3D.RESTITUTION
+    if use_gravity:
+        spec["fext"][:, s_, 4] = -10.0
     params = {}
     if torch.is_tensor(radii) and radii.requires_grad:
-        r = radii.to(torch.float64)
+        r = radii.to(torch.float64).reshape(-1)
         prm = torch.tensor(spec["shape_prm"], dtype=torch.float64)
-        prm = torch.cat([prm[:, :1], torch.stack([r, torch.zeros_like(r), torch.zeros_like(r)], 1)[:, None].to(prm)], 1)
+        prm = torch.cat([prm[:, :s_], torch.stack([r, torch.zeros_like(r), torch.zeros_like(r)], 1)[:, None].to(prm)], 1)
         inertia = torch.tensor(spec["inertia"], dtype=torch.float64)
         ball = (0.4 * r * r)[:, None, None].to(inertia) * torch.eye(3, dtype=torch.float64)      # 2/5 m r^2 (bodies.py:993-994)
-        inertia = torch.cat([inertia[:, :1], ball[:, None]], 1)
-        params = dict(shape_prm=prm, inertia=inertia)
-    return BatchWorld3D(spec, params=params, time_of_contact_diff=toc, max_substeps=4 * steps + 64, device=device)
+        params = dict(shape_prm=prm, inertia=torch.cat([inertia[:, :s_], ball[:, None]], 1))
+    steps = int(math.ceil(run_time / dt)) + 2
+    return BatchWorld3D(spec, params=params, dt=dt, time_of_contact_diff=use_toc_diff, max_substeps=8 * steps + 64, device=device)
 
 
-def fit_sphere_radius(target_radii, init_radii, y0, vx, steps=30, iters=20, lr=0.05, log=None):
-    """Adam on the radius of every scene at once (optim_sphere.py:163-250 runs one scene per process; its per-parameter
-    step normalisation keeps the scenes of the batch independent of each other).  A new world is built from the current
-    estimate in every iteration, like the reference's make_world."""
+def fit_sphere_radius(target_radii, start_radii, run_time=1.5, max_iter=100, lr=0.1, conv_thresh=1e-5, min_dim=0.4, max_dim=2.0,
+                      detach_2nd_bounce=True, log=None, **scene):
+    """The loop of optim_sphere.py:210-270 for B scenes at once: plain gradient descent on the radius, a new world from the
+    current estimate in every iteration, a scene stops when its loss changes by less than conv_thresh (its radius is frozen:
+    the scenes of the batch are independent optimisations).  Returns dict(radius [B], history)."""
+    target_radii = torch.as_tensor(np.asarray(target_radii, np.float64))
     with torch.no_grad():
-        target_pose, _ = rollout(sphere_world(torch.as_tensor(target_radii), y0, vx, steps=steps), steps)
-    rad = torch.tensor(np.asarray(init_radii, np.float64), requires_grad=True)
-    opt = torch.optim.Adam([rad], lr=lr)
+        target = run_world_fixed_dt(bounce_world(target_radii, run_time=run_time, **scene), run_time)
+    rad = torch.tensor(np.asarray(start_radii, np.float64), requires_grad=True)
+    B = rad.numel()
+    done = np.zeros(B, bool)
+    last = np.full(B, 1e10)
     hist = []
-    for it in range(iters):
-        opt.zero_grad()
-        world = sphere_world(rad, y0, vx, steps=steps)
-        pose, _ = rollout(world, steps)
-        loss = trajectory_loss(pose, target_pose)
+    for e in range(max_iter):
+        if rad.grad is not None:
+            rad.grad = None
+        world = bounce_world(rad, run_time=run_time, **scene)
+        traj = run_world_fixed_dt(world, run_time, detach_2nd_bounce=detach_2nd_bounce)
+        loss = trajectory_loss(traj, target)
         loss.sum().backward()
-        hist.append(dict(iter=it, loss=loss.detach().cpu().numpy().copy(), radius=rad.detach().numpy().copy(),
-                         grad=rad.grad.numpy().copy()))
+        l = loss.detach().cpu().numpy()
+        done |= np.abs(last - l) < conv_thresh
+        hist.append(dict(iter=e, loss=l.copy(), radius=rad.detach().numpy().copy(), grad=rad.grad.numpy().copy(), done=done.copy()))
         if log:
-            log("iter %2d  mean loss %.3e  mean |r - r*| %.4f" % (it, float(loss.detach().mean()), float((rad.detach() - torch.as_tensor(target_radii)).abs().mean())))
-        opt.step()
+            log("iter %3d  mean loss %.3e  mean |r - r*| %.4f  converged %d / %d" %
+                (e, float(l.mean()), float((rad.detach() - target_radii).abs().mean()), int(done.sum()), B))
+        if done.all():
+            break
         with torch.no_grad():
-            rad.clamp_(0.2, 0.9)
-    return hist, target_pose
+            step = lr * rad.grad
+            step[torch.as_tensor(done)] = 0.0
+            rad -= step
+            rad.clamp_(min_dim, max_dim)
+        last = l
+    return dict(radius=rad.detach().numpy().copy(), target=target_radii.numpy(), history=hist)
+
+
+def radius_error_table(results):
+    """min / mean / max of |r - r*| per variant, the numbers of RESULTS.md:14-47."""
+    rows = []
+    for name, r in results.items():
+        err = np.abs(r["radius"] - r["target"])
+        rows.append("%-22s min %.1e  mean %.4f  max %.4f   (%d scenes)" % (name, err.min(), err.mean(), err.max(), len(err)))
+    return "\n".join(rows)
+
+
+# ---- inertia fitting: a neural-SDF body spun by a torque (optim_shapespace.py) ------------------------------------------------
+def spin_world(latents, torque_dirs, packed, scale=1.0, mass=1.0, res=128, steps=64, device=None):
+    """optim_shapespace.py:71-92 for one scene per latent code: a single neural-SDF body (scale 1) whose translation is locked
+    by X/Y/Z constraints; no contacts, so only its inertia matters -- integrated over its level-set mesh (MeshSDF:
+    differentiable w.r.t. the latent).  The torque (t < 0.3) is applied by the caller through world.params['fext']."""
+    B = latents.shape[0]
+    Is, ms = [], []
+    for s in range(B):
+        v, f = meshsdf.igr_mesh(latents[s], packed, res=res)
+        vt = v * scale
+        Is.append(mass_properties.mesh_inertia_diff(vt, f, torch.tensor(float(mass), dtype=torch.float64)).cpu())
+        ms.append((vt.detach().cpu().numpy(), f.cpu().numpy()))
+    inertia = torch.stack(Is)[:, None]                                        # [B,1,3,3], graph to the latents
+    one = lambda a: np.tile(np.asarray(a, np.float64), (B, 1, 1))
+    spec = dict(pose=one([1.0, 0, 0, 0, 0, 0, 0]), vel=one(np.zeros(6)), mass=np.full((B, 1), float(mass)),
+                inertia=inertia.detach().numpy(), restitution=np.zeros((B, 1)), fric=np.zeros((B, 1)), fext=np.zeros((B, 1, 6)),
+                shape_type=np.full((B, 1), abi.SHAPE_SPHERE, np.int32), shape_prm=one([scale, 0, 0]),      # (nothing collides: the shape is never queried)
+                mesh_id=np.arange(B, dtype=np.int32)[:, None], meshes=ms, mesh_vgrad=[np.zeros_like(m[0]) for m in ms],
+                Je=np.tile(np.concatenate([np.zeros((3, 3)), np.eye(3)], 1), (B, 1, 1)), no_contact=np.zeros((1, 1), np.uint8))
+    w = BatchWorld3D(spec, params=dict(inertia=inertia), max_substeps=steps + 16, device=device)
+    w.meshes = ms
+    return w
+
+
+def run_spin(world, torque_dirs, run_time=2.0, torque_time=0.3):
+    """`run_world(world, run_time=...)` with the experiment's force function: torque_dir for t < 0.3, then nothing."""
+    B = world.B
+    tq = torch.cat([torch.as_tensor(torque_dirs, dtype=torch.float64), torch.zeros(B, 3, dtype=torch.float64)], 1)[:, None]
+    while float(world.t.min()) < run_time:
+        world.params["fext"] = tq if float(world.t.min()) < torque_time else torch.zeros_like(tq)
+        world.step()
+    return world.vel[:, 0]
+
+
+def fit_inertia_latent(target_latents, start_latents, torque_dirs, packed, run_time=2.0, max_iter=20, lr=1e-2, latent_reg=0.0,
+                       conv_thresh=1e-7, res=128, log=None):
+    """optim_shapespace.py:136-250: gradient descent on the latent code so that the body's final velocity under the torque
+    matches the target's.  The gradient runs latent -> level-set mesh (MeshSDF) -> volume integrals -> world-frame inertia ->
+    linear solve of every step."""
+    steps = int(math.ceil(run_time / Defaults3D.DT)) + 2
+    with torch.no_grad():
+        wt = spin_world(torch.as_tensor(target_latents, dtype=torch.float64), torque_dirs, packed, res=res, steps=steps)
+        v_target = run_spin(wt, torque_dirs, run_time).clone()
+    lat = torch.tensor(np.asarray(start_latents, np.float64), requires_grad=True)
+    hist, last = [], None
+    for e in range(max_iter):
+        if lat.grad is not None:
+            lat.grad = None
+        w = spin_world(lat, torque_dirs, packed, res=res, steps=steps)
+        v = run_spin(w, torque_dirs, run_time)
+        loss = ((v - v_target.to(v)) ** 2).sum(dim=1) + latent_reg * (lat.to(v.device) ** 2).sum(dim=1)
+        loss.sum().backward()
+        l = loss.detach().cpu().numpy()
+        d = np.array([float(chamfer(torch.as_tensor(a[0]), torch.as_tensor(b[0]))) for a, b in zip(w.meshes, wt.meshes)])
+        hist.append(dict(iter=e, loss=l.copy(), latent=lat.detach().numpy().copy(), grad=lat.grad.numpy().copy(), chamfer=d))
+        if log:
+            log("iter %3d  mean loss %.3e  mean chamfer %.3e  |grad| %.3e" % (e, float(l.mean()), float(d.mean()), float(lat.grad.abs().mean())))
+        if last is not None and np.all(np.abs(last - l) < conv_thresh):
+            break
+        with torch.no_grad():
+            lat -= lr * lat.grad
+        last = l
+    return dict(latent=lat.detach().numpy().copy(), target=np.asarray(target_latents), history=hist)
 
 
 def export_trajectory(path, pose, vel, **meta):
@@ -99,21 +261,30 @@ def export_trajectory(path, pose, vel, **meta):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="batched sphere-radius fitting (trajectory_fitting/optim_sphere, all scenes at once)")
+    ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace)")
+    ap.add_argument("what", choices=["sphere", "inertia"])
     ap.add_argument("--scenes", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--iters", type=int, default=15)
-    ap.add_argument("--lr", type=float, default=0.03)
+    ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
     r = np.random.default_rng(a.seed)
-    target = 0.4 + 0.2 * r.random(a.scenes)
-    init = target + 0.08 * (r.random(a.scenes) - 0.5)
-    y0, vx = 0.7 + 0.5 * r.random(a.scenes), r.random(a.scenes)
-    hist, target_pose = fit_sphere_radius(target, init, y0, vx, steps=a.steps, iters=a.iters, lr=a.lr, log=print)
-    if a.out:
-        np.savez_compressed(a.out, target=target, init=init, radius=np.stack([h["radius"] for h in hist]), loss=np.stack([h["loss"] for h in hist]))
+    if a.what == "sphere":
+        # RESULTS.md:14-47: radius error after fitting, target and start radii ~ U(0.4, 2.0) (optim_sphere.py:214-218)
+        target, start = 0.4 + 1.6 * r.random(a.scenes), 0.4 + 1.6 * r.random(a.scenes)
+        res = {}
+        for name, kw in (("gravity, no toc", dict(use_toc_diff=False)), ("gravity, toc", dict(use_toc_diff=True)),
+                         ("no gravity, toc", dict(use_toc_diff=True, use_gravity=False))):
+            res[name] = fit_sphere_radius(target, start, max_iter=a.iters, log=lambda s, n=name: print("[%s] %s" % (n, s)), **kw)
+        print(radius_error_table(res))
+        if a.out:
+            np.savez_compressed(a.out, **{k.replace(" ", "_").replace(",", ""): v["radius"] for k, v in res.items()}, target=target, start=start)
+    else:
+        from . import igr
+        packed = igr.pack_weights(*scenes.geometric_init_weights(a.seed, 0.5))
+        tgt, st = 0.1 * r.standard_normal((a.scenes, 2)), 0.1 * r.standard_normal((a.scenes, 2))
+        dirs = r.standard_normal((a.scenes, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        fit_inertia_latent(tgt, st, dirs, packed, max_iter=a.iters, log=print)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ PARAMS = ("mass", "inertia", "restitution", "fric", "fext", "shape_prm")
 
 class _StepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm, verts=None):
+    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm, verts=None, mask=None):
         # verts: the mesh table's vertices [NV,3] as a differentiable input (level-set meshes: their shape gradient flows
         # through the vertex positions); the engine already holds their values, only the adjoint is produced
         E = world.engine
@@ -38,7 +38,7 @@ class _StepFn(torch.autograd.Function):
             E.arr[name].copy_(t.detach().reshape(E.arr[name].shape))
             seen[name] = (t, t._version)
         nsub0 = E.arr["nsub"].clone()
-        att = E.step() if fixed_dt else E.step_once()
+        att = E.step(mask=mask) if fixed_dt else E.step_once()
         ctx.world, ctx.nsub0, ctx.att = world, nsub0, att
         ctx.nsub1 = E.arr["nsub"].clone()      # tape slots [nsub0, nsub1) belong to this node
         ctx.index = world._n_nodes
@@ -71,7 +71,7 @@ class _StepFn(torch.autograd.Function):
         E.backward_sweep(ctx.att + (1 if first else 0))
         return (None, None, adj["a_pose"].clone(), adj["a_vel"].clone(), adj["g_mass"].clone(),
                 adj["g_inertia"].reshape(E.B, E.nb, 3, 3).clone(), adj["g_rest"].clone(), adj["g_fric"].clone(),
-                adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None)
+                adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None, None)
 
 
 class BatchWorld3D:
@@ -102,7 +102,15 @@ class BatchWorld3D:
     def t(self):
         return self.engine.get("t")
 
-    def step(self, fixed_dt=True):
+    _UNDO_ARRAYS = ("t", "nc", "c_body", "c_face", "c_abc", "c_geom", "last_dt", "toc", "nsub")
+
+    def step(self, fixed_dt=True, mask=None):
+        """One outer step for every scene, or with `mask` ([B] booleans) for the selected scenes only (the others keep their
+        state and time).  Returns [B] booleans: contacts present afterwards (World.step's `had_contacts`, world.py:119-139)."""
+        E = self.engine
+        self._start_batch = (self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS})
+        if mask is not None:
+            mask = np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(np.int32)
         P = self.params
         dev_cache = self.__dict__.setdefault("_dev_params", {})
 
@@ -117,10 +125,27 @@ class BatchWorld3D:
         self.pose, self.vel = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
                                             to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
                                             to("fext", P["fext"]), to("shape_prm", P["shape_prm"]),
-                                            to("verts", P["verts"]) if P.get("verts") is not None else None)
+                                            to("verts", P["verts"]) if P.get("verts") is not None else None, mask)
         up = self.__dict__.setdefault("_uploaded", {})
         up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
-        return self.engine.get("nc") > 0
+        return self.engine.get("had_contacts") > 0
+
+    def undo_step(self, mask):
+        """`World.undo_step` (lcp_physics/physics/world.py:106-116) for the scenes `mask` selects: time, poses, velocities
+        (with their graph) and contacts go back to the start of the last step; the other scenes keep what they have."""
+        pose0, vel0, arrs = self._start_batch
+        m = torch.as_tensor(np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(bool), device=self.device)
+        E = self.engine
+        for k, a in arrs.items():
+            E.arr[k][m] = a[m]
+        self.pose = torch.where(m[:, None, None], pose0.to(self.device), self.pose)
+        self.vel = torch.where(m[:, None, None], vel0.to(self.device), self.vel)
+
+    def detach_state(self, mask):
+        """Cut the graph of the selected scenes' poses and velocities (optim_sphere.py:170-175: `detach_2nd_bounce`)."""
+        m = torch.as_tensor(np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(bool), device=self.device)
+        self.pose = torch.where(m[:, None, None], self.pose.detach(), self.pose)
+        self.vel = torch.where(m[:, None, None], self.vel.detach(), self.vel)
 
     def contact_pairs(self, s=0):
         nc = int(self.engine.get("nc")[s])

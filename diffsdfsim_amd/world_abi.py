@@ -26,7 +26,7 @@ FIELDS = [
     ("fch_box", "pd"), ("vch_box", "pd"), ("mesh_fch_off", "pi"), ("mesh_vch_off", "pi"),
     ("Je", "pd"), ("b_eq", "pd"),
     ("t", "pd"), ("t_end", "pd"), ("dt_try", "pd"), ("last_dt", "pd"), ("dt_use", "pd"),
-    ("active", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
+    ("active", "pi"), ("step_mask", "pi"), ("had_contacts", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
     ("nc", "pi"), ("c_body", "pi"), ("c_face", "pi"), ("c_abc", "pd"), ("c_geom", "pd"),
     ("n_nc", "pi"), ("n_body", "pi"), ("n_face", "pi"), ("n_abc", "pd"), ("n_geom", "pd"),
     ("pose0", "pd"), ("vel0", "pd"),
@@ -86,7 +86,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
         "fch_box": (NFC, 6), "vch_box": (NVC, 6), "mesh_fch_off": (nmesh,), "mesh_vch_off": (nmesh,),
         "Je": (B, max(neq, 1), nz), "b_eq": (B, max(neq, 1)),
         "t": (B,), "t_end": (B,), "dt_try": (B,), "last_dt": (B,), "dt_use": (B,),
-        "active": (B,), "toc": (B,), "nsub": (B,), "n_active": (1,),
+        "active": (B,), "had_contacts": (B,), "toc": (B,), "nsub": (B,), "n_active": (1,),
         "nc": (B,), "c_body": (B, 2, maxc), "c_face": (B, maxc), "c_abc": (B, 3, maxc), "c_geom": (B, 10, maxc),
         "n_nc": (B,), "n_body": (B, 2, maxc), "n_face": (B, maxc), "n_abc": (B, 3, maxc), "n_geom": (B, 10, maxc),
         "pose0": (B, nb, 7), "vel0": (B, nb, 6),

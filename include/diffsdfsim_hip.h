@@ -154,6 +154,10 @@ typedef struct DssWorld {
     double *t, *t_end, *dt_try, *last_dt;
     double *dt_use;  /* dt_ actually integrated in the current attempt (world.py:251-257) */
     int *active;     /* 1 while t < t_end in the current outer step */
+    const int *step_mask;  /* optional [B]: scenes with 0 sit the next outer step out (dss_step_begin leaves them inactive): a
+                              batch whose scenes are at different times, e.g. after a per-scene undo (optim_sphere.py:163-177) */
+    int *had_contacts;  /* [B] any accepted sub-step of the current outer step ended with contacts (World.step's return value,
+                           world.py:127-139) */
     int *toc;        /* reference's `toc_contacts` non-empty */
     int *nsub;       /* accepted sub-steps so far (tape slot) */
     int *n_active;   /* [1] number of scenes still active after dss_step_decide | DSS_N_ACTIVE_OVERFLOW */

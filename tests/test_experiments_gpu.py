@@ -1,5 +1,5 @@
-"""GPU: batched experiment driver (diffsdfsim_amd/experiments.py) -- trajectory fitting of the sphere
-radius for many scenes at once, as `experiments/trajectory_fitting/optim_sphere.py` does for one."""
+"""GPU: batched experiment drivers (diffsdfsim_amd/experiments.py): the loops of
+`experiments/trajectory_fitting/optim_sphere.py` and `experiments/inertia_fitting/optim_shapespace.py` for many scenes at once."""
 import numpy as np
 import pytest
 import torch
@@ -7,19 +7,65 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_batched_radius_fitting_recovers_the_targets(tmp_path):
+def test_bounce_scene_undo_and_detach_are_per_scene():
+    """`run_world_fixed_dt(..., detach_2nd_bounce)` (optim_sphere.py:163-177) on a batch whose scenes hit floor and wall in
+    different steps: every scene ends at the same time having taken its own number of outer steps (an undone step is redone),
+    and a scene run alone goes through exactly the same states."""
     from diffsdfsim_amd import experiments as X
-    r = np.random.default_rng(3)
-    B = 12
-    target = 0.45 + 0.1 * r.random(B)
-    init = target + np.where(r.random(B) < 0.5, -0.04, 0.04)
-    y0, vx = 0.75 + 0.3 * r.random(B), 0.5 * r.random(B)
-    hist, target_pose = X.fit_sphere_radius(target, init, y0, vx, steps=20, iters=12, lr=0.01)
-    e0, e1 = np.abs(hist[0]["radius"] - target), np.abs(hist[-1]["radius"] - target)
-    assert np.isfinite(hist[-1]["grad"]).all()
-    assert hist[-1]["loss"].mean() < 0.25 * hist[0]["loss"].mean(), (hist[0]["loss"].mean(), hist[-1]["loss"].mean())
-    assert e1.mean() < 0.5 * e0.mean(), (e0.mean(), e1.mean())
-    # the gradient points the right way in every scene from the first iteration on (too small a sphere hits the floor late)
-    assert (np.sign(hist[0]["grad"]) == np.sign(init - target)).all()
-    X.export_trajectory(tmp_path / "traj.npz", target_pose, torch.zeros(target_pose.shape[:3] + (6,), dtype=target_pose.dtype, device=target_pose.device))
-    assert np.load(tmp_path / "traj.npz")["trajectory"].shape == (20, B, 2, 13)
+    rad = torch.tensor([0.5, 0.9, 1.4, 0.7], dtype=torch.float64)
+    tr = X.run_world_fixed_dt(X.bounce_world(rad, run_time=1.0), 1.0, detach_2nd_bounce=True)
+    assert tr["valid"].shape[1] == 4 and bool((tr["t"][-1] >= 1.0 - 1e-9).all())
+    n_valid = tr["valid"].sum(dim=0).cpu().numpy()
+    # 30 outer steps of 1/30 s -- 31 where the accumulated time falls a rounding error short of 1.0, as in the reference's
+    # `while world.t < run_time` -- for every scene, however many of its steps were redone
+    assert (n_valid == n_valid[0]).all() and n_valid[0] in (30, 31), n_valid
+    assert tr["valid"].shape[0] > n_valid[0], "some step was meant to be undone and redone (second contact step in a row)"
+    one = X.run_world_fixed_dt(X.bounce_world(rad[2:3], run_time=1.0), 1.0, detach_2nd_bounce=True)
+    a = tr["pose"][:, 2][tr["valid"][:, 2]]
+    b = one["pose"][:, 0][one["valid"][:, 0]]
+    assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_radius_fitting_on_the_bounce_scene():
+    """The gradient-descent loop of optim_sphere.py:210-270 for eight (target, start) pairs at once: losses fall, radii move
+    towards their targets, the chamfer distance between the fitted and the target sphere shrinks with them."""
+    from diffsdfsim_amd import experiments as X, meshes
+    r = np.random.default_rng(5)
+    B = 8
+    target = 0.5 + 0.8 * r.random(B)
+    start = target + np.where(r.random(B) < 0.5, -0.15, 0.15)
+    res = X.fit_sphere_radius(target, start, run_time=1.0, max_iter=12, lr=0.1)
+    h = res["history"]
+    e0, e1 = np.abs(start - target), np.abs(res["radius"] - target)
+    assert np.isfinite(h[-1]["grad"]).all()
+    assert h[-1]["loss"].mean() < 0.5 * h[0]["loss"].mean(), (h[0]["loss"].mean(), h[-1]["loss"].mean())
+    assert e1.mean() < 0.7 * e0.mean(), (e0.mean(), e1.mean())
+    uv, _ = meshes.icosphere(3)
+    uv = torch.as_tensor(uv)
+    d0 = float(X.chamfer(uv * start[0], uv * target[0])); d1 = float(X.chamfer(uv * res["radius"][0], uv * target[0]))
+    assert (d1 < d0) == (e1[0] < e0[0])
+    print(X.radius_error_table({"gravity, toc (8 scenes, 12 iterations)": res}))
+
+
+def test_trajectory_loss_pairs_by_nearest_time():
+    from diffsdfsim_amd import experiments as X
+    t = torch.tensor([[0.1], [0.2], [0.2], [0.3]], dtype=torch.float64)
+    mk = lambda pos, valid: dict(t=t, pose=torch.cat([torch.zeros(4, 1, 1, 4, dtype=torch.float64), pos], dim=3), vel=None,
+                                 valid=torch.tensor(valid)[:, None])
+    tgt = mk(torch.tensor([1.0, 2.0, 9.0, 3.0], dtype=torch.float64).reshape(4, 1, 1, 1).expand(4, 1, 1, 3), [True, True, False, True])
+    src = mk(torch.tensor([1.5, 9.0, 2.5, 3.5], dtype=torch.float64).reshape(4, 1, 1, 1).expand(4, 1, 1, 3), [True, False, True, True])
+    # valid entries 0, 2, 3 at t = .1, .2, .3 against target values 1, 2, 3: three coordinates each 0.5 off
+    assert abs(float(X.trajectory_loss(src, tgt)[0]) - 0.75) < 1e-12
+
+
+def test_inertia_fitting_gradient_reaches_the_latent_code():
+    """optim_shapespace.py:136-250 for two scenes, low mesh resolution: the loss (final angular velocity under the torque)
+    falls, the gradient arrives at the latent code through mesh, volume integrals and every step's linear solve."""
+    from diffsdfsim_amd import experiments as X, igr, scenes
+    packed = igr.pack_weights(*scenes.geometric_init_weights(0, 0.5))
+    tgt = np.array([[0.05, -0.08], [-0.06, 0.03]]); st = tgt + np.array([[0.06, 0.05], [0.05, -0.06]])
+    dirs = np.array([[1.0, 0.0, 0.0], [0.0, 0.6, 0.8]])
+    res = X.fit_inertia_latent(tgt, st, dirs, packed, run_time=0.5, max_iter=4, lr=2e-2, res=48)
+    h = res["history"]
+    assert np.isfinite(h[0]["grad"]).all() and np.abs(h[0]["grad"]).max() > 0
+    assert h[-1]["loss"].sum() < h[0]["loss"].sum(), ([x["loss"] for x in h])
