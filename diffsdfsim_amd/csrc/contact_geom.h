@@ -27,6 +27,8 @@ template <class T> __host__ __device__ inline double lap_probe(const Shape<T> &s
 #if DSS_ALL_SHAPES
     sd.hr = val(s.hr);
     sd.lin = nullptr;
+    sd.grid = s.grid;
+    for (int i = 0; i < 3; ++i) sd.gn[i] = s.gn[i];
 #endif
     double acc = 0.0, pt[3] = {val(p[0]), val(p[1]), val(p[2])}, g[3];
     for (int i = 0; i < 3; ++i) {

@@ -287,7 +287,7 @@ inline namespace shapes_all {
 #else
 inline namespace shapes_lean {
 #endif
-enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2, SHAPE_BOX_ROUNDED = 3, SHAPE_BRICK = 4, SHAPE_BOWL = 5, SHAPE_IGR = 6 };
+enum ShapeType { SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CYLINDER = 2, SHAPE_BOX_ROUNDED = 3, SHAPE_BRICK = 4, SHAPE_BOWL = 5, SHAPE_IGR = 6, SHAPE_GRID = 7 };
 
 template <class T> struct Shape {
     int type;
@@ -299,6 +299,9 @@ template <class T> struct Shape {
     // neural SDF (SHAPE_IGR) in the reverse sweep: records of the network's value and derivatives at the points this body is
     // queried at for ONE contact (igr_lin below), evaluated beforehand on the matrix cores; NULL elsewhere
     const double *lin;
+    // voxel-grid SDF (SHAPE_GRID, SDFGrid3D bodies.py:203-257, 763-775): samples over the unit cube, x slowest
+    const double *grid;
+    int gn[3];
 #endif
 };
 // aux: the corner radius r of SDFBoxRounded / SDFBrick (a constant of the body; bodies.py:857-885), unused otherwise
@@ -309,6 +312,8 @@ template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int t
 #if DSS_ALL_SHAPES
     s.hr = T(0.0);
     s.lin = nullptr;
+    s.grid = nullptr;
+    s.gn[0] = s.gn[1] = s.gn[2] = 0;
 #endif
     if (type == SHAPE_BOX) {
         s.scale = t_max(t_max(prm[0], prm[1]), prm[2]) * 1.5 / 2.0;
@@ -331,7 +336,7 @@ template <class T> __host__ __device__ inline void make_shape(Shape<T> &s, int t
     } else if (type == SHAPE_BOWL) {       // bodies.py:1013-1027: scale = (r + d) * 1.3333, params r/scale, d/scale
         s.scale = (prm[0] + prm[1]) * 1.3333;
         s.hd[0] = prm[0] / s.scale; s.hd[1] = prm[1] / s.scale; s.hd[2] = T(0.0);
-    } else if (type == SHAPE_IGR) {        // SDF3D with a network (bodies.py:627-651): prm = latent code, aux = the given scale
+    } else if (type == SHAPE_IGR || type == SHAPE_GRID) {   // SDF3D with a network / a voxel grid (bodies.py:627-651, 763-775): aux = the given scale
         s.scale = T(aux);
         for (int i = 0; i < 3; ++i) s.hd[i] = T(0.0);
 #endif
@@ -351,6 +356,8 @@ template <class T> __host__ __device__ inline void make_unit_shape(Shape<T> &s, 
     s.scale = T(1.0);
     s.hr = au;
     s.lin = nullptr;
+    s.grid = nullptr;
+    s.gn[0] = s.gn[1] = s.gn[2] = 0;
     if (type == SHAPE_BOX) for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0;          // box_sdf: half_dims = dims / 2
     else if (type == SHAPE_BOX_ROUNDED) for (int i = 0; i < 3; ++i) s.hd[i] = (pu[i] - au * 2.0) / 2.0;
     else if (type == SHAPE_BRICK) { for (int i = 0; i < 3; ++i) s.hd[i] = pu[i] / 2.0; s.hd[0] = s.hd[0] - au; s.hd[1] = s.hd[1] - au; }
@@ -477,6 +484,43 @@ template <class T> __host__ __device__ inline void sdf_unit(const Shape<T> &s, c
         }
 #endif
 #if DSS_ALL_SHAPES
+    } else if (s.type == SHAPE_GRID) {
+        // grid_sdf / grid_sdf_grad (bodies.py:203-241): value = trilinear interpolation of the samples at index position
+        // (p + 1)/2 (n - 1); gradient = the interpolated central-difference field (zero on the boundary layers), normalised
+        // (twice, like every analytic gradient: once by grid_sdf_grad, once by query_sdfs).  `grid_interp` of the un-vendored
+        // ev_sdf_utils is restated as plain trilinear interpolation.  To autograd the value's derivative w.r.t. the point IS
+        // that normalised gradient (DiffGridSDF.backward, bodies.py:244-257) and the gradient itself carries no graph.
+        const int n0 = s.gn[0], n1 = s.gn[1], n2 = s.gn[2];
+        const int nn[3] = {n0, n1, n2};
+        int i0[3];
+        double w[3];
+        for (int d = 0; d < 3; ++d) {
+            const double ind = (val(p[d]) + 1.0) * 0.5 * (double)(nn[d] - 1);
+            int c = (int)floor(ind);
+            c = c < 0 ? 0 : (c > nn[d] - 2 ? nn[d] - 2 : c);
+            i0[d] = c; w[d] = ind - (double)c;
+        }
+        const double *Gd = s.grid;
+        auto at = [&](int i, int j, int k) { return Gd[((size_t)i * n1 + j) * n2 + k]; };
+        double pv = 0.0, gv[3] = {0.0, 0.0, 0.0};
+        for (int dx = 0; dx < 2; ++dx)
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dz = 0; dz < 2; ++dz) {
+                    const double wt = (dx ? w[0] : 1.0 - w[0]) * (dy ? w[1] : 1.0 - w[1]) * (dz ? w[2] : 1.0 - w[2]);
+                    const int i = i0[0] + dx, j = i0[1] + dy, k = i0[2] + dz;
+                    pv = pv + at(i, j, k) * wt;
+                    const double cx = (i == 0 || i == n0 - 1) ? 0.0 : (at(i + 1, j, k) - at(i - 1, j, k)) / 2.0;
+                    const double cy = (j == 0 || j == n1 - 1) ? 0.0 : (at(i, j + 1, k) - at(i, j - 1, k)) / 2.0;
+                    const double cz = (k == 0 || k == n2 - 1) ? 0.0 : (at(i, j, k + 1) - at(i, j, k - 1)) / 2.0;
+                    gv[0] = gv[0] + cx * wt; gv[1] = gv[1] + cy * wt; gv[2] = gv[2] + cz * wt;
+                }
+        double g1[3], g2[3];
+        normalize(gv, g1);
+        normalize(g1, g2);
+        T acc = T(pv);
+        for (int i = 0; i < 3; ++i) acc = acc + (p[i] - val(p[i])) * g1[i];
+        phi = acc;
+        if (want_grad) for (int i = 0; i < 3; ++i) g[i] = T(g2[i]);
     } else if (s.type == SHAPE_IGR) {
         // a network is never evaluated lane by lane: its queries go through the matrix-core rounds (narrowphase_igr.hip,
         // igr_mlp.hip).  Reaching this branch is a bug; make it loud.

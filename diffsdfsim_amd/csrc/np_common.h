@@ -61,6 +61,13 @@ __device__ inline void load_body(const DssWorld &W, int sc, int b, BodyD &o)
     o.g.shape.hr = dss_uniform(o.g.shape.hr);
 #endif
     o.g.shape.type = dss_uniform(o.g.shape.type);
+#if DSS_ALL_SHAPES
+    if (o.g.shape.type == SHAPE_GRID && W.grid_id) {
+        const int gi = W.grid_id[(size_t)sc * W.nb + b];
+        o.g.shape.grid = W.grid_data + W.grid_off[gi];
+        for (int i = 0; i < 3; ++i) o.g.shape.gn[i] = W.grid_dims[3 * gi + i];
+    }
+#endif
     o.mesh = W.mesh_id[(size_t)sc * W.nb + b];
     o.voff = W.mesh_voff[o.mesh]; o.nv = W.mesh_nv[o.mesh];
     o.foff = W.mesh_foff[o.mesh]; o.nf = W.mesh_nf[o.mesh];

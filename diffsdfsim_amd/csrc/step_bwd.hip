@@ -89,6 +89,15 @@ __device__ inline void bwd_select(const DssWorld &W, const DssAdjoint &A, int sc
 // SDF queries and the Newton step): they take two full passes.  q2, x2 and prm2 enter the body-2 half alone
 // (contact_tail: one query, two rotations), so their three passes differentiate that half with the head as constants;
 // x1 appears only in rel = p1 + x1 - x2, hence d/dx1 = -d/dx2 and needs no pass of its own.
+#if DSS_ALL_SHAPES
+template <class T> __device__ inline void attach_grid(const DssWorld &W, int sc, int b, Shape<T> &s)
+{
+    if (s.type != SHAPE_GRID || !W.grid_id) return;
+    const int gi = W.grid_id[(size_t)sc * W.nb + b];
+    s.grid = W.grid_data + W.grid_off[gi];
+    for (int i = 0; i < 3; ++i) s.gn[i] = W.grid_dims[3 * gi + i];
+}
+#endif
 // lin1 / lin2: igr_lin records of a neural body 1 / body 2 for this contact (NULL: analytic body); stable_in >= 0: which
 // body's normal the contact used, decided by the caller (for neural bodies the Laplacian probes are not repeated).
 __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
@@ -122,7 +131,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         make_shape(B1.shape, ty1, prm1, aux1);
         make_shape(B2.shape, ty2, prm2, aux2);
 #if DSS_ALL_SHAPES
-        B1.shape.lin = lin1; B2.shape.lin = lin2;
+        B1.shape.lin = lin1; B2.shape.lin = lin2; attach_grid(W, sc, b1, B1.shape); attach_grid(W, sc, b2, B2.shape);
 #endif
         double nn[3], pp2[3], pen;
         contact_head(B1, tv, abc, cp1v, n1v, d1v, p1v);
@@ -150,7 +159,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         make_shape(B1.shape, ty1, pr1, aux1);
         make_shape(B2.shape, ty2, pr2, aux2);
 #if DSS_ALL_SHAPES
-        B1.shape.lin = lin1; B2.shape.lin = lin2;
+        B1.shape.lin = lin1; B2.shape.lin = lin2; attach_grid(W, sc, b1, B1.shape); attach_grid(W, sc, b2, B2.shape);
 #endif
         D tri[3][3];
         for (int v = 0; v < 3; ++v)
@@ -184,7 +193,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
         make_shape(B1.shape, ty1, pr1, aux1);
         make_shape(B2.shape, ty2, pr2, aux2);
 #if DSS_ALL_SHAPES
-        B1.shape.lin = lin1; B2.shape.lin = lin2;
+        B1.shape.lin = lin1; B2.shape.lin = lin2; attach_grid(W, sc, b1, B1.shape); attach_grid(W, sc, b2, B2.shape);
 #endif
         D cp1[3], n1[3], d1(d1v), p1[3], n[3], p2[3], pen;
         for (int i = 0; i < 3; ++i) { cp1[i] = D(cp1v[i]); n1[i] = D(n1v[i]); p1[i] = D(p1v[i]); }
@@ -206,7 +215,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
             make_shape(B1.shape, ty1, pr1, aux1);
             make_shape(B2.shape, ty2, pr2, aux2);
 #if DSS_ALL_SHAPES
-            B1.shape.lin = lin1; B2.shape.lin = lin2;
+            B1.shape.lin = lin1; B2.shape.lin = lin2; attach_grid(W, sc, b1, B1.shape); attach_grid(W, sc, b2, B2.shape);
 #endif
             D tri[3][3];
             for (int v = 0; v < 3; ++v)

@@ -60,7 +60,7 @@ def default_vgrad(shape_type, prm, verts):
     Box: only coordinates that ARE +-dims/2 carry a gradient (the reference re-ties the linspace ends),
     d v_k / d dims_k = sign/2.  Sphere: verts = unit * rad, d v / d rad = v / rad."""
     verts = np.asarray(verts, np.float64)
-    if shape_type in (abi.SHAPE_BOX_ROUNDED, abi.SHAPE_BRICK, abi.SHAPE_BOWL, abi.SHAPE_IGR):
+    if shape_type in (abi.SHAPE_BOX_ROUNDED, abi.SHAPE_BRICK, abi.SHAPE_BOWL, abi.SHAPE_IGR, abi.SHAPE_GRID):
         return np.zeros_like(verts)   # level-set / two-parameter meshes: no per-vertex parameter tangent in this layout
     if shape_type == abi.SHAPE_BOX:
         hd = np.asarray(prm, np.float64)[:3] / 2
@@ -157,6 +157,12 @@ class BatchEngine:
         if "shape_aux" in spec:
             host["shape_aux"] = spec["shape_aux"]
         host["no_contact"] = np.asarray(spec.get("no_contact", np.zeros((nb, nb))), np.uint8)
+        if spec.get("grids"):      # voxel-grid SDF bodies: pooled table of their sample grids
+            gs = [np.ascontiguousarray(np.asarray(g, np.float64)) for g in spec["grids"]]
+            off = np.cumsum([0] + [g.size for g in gs[:-1]]).astype(np.int32)
+            shapes.update(grid_id=(B, nb), grid_off=(len(gs),), grid_dims=(len(gs), 3), grid_data=(int(sum(g.size for g in gs)),))
+            host.update(grid_id=np.asarray(spec["grid_id"], np.int32), grid_off=off,
+                        grid_dims=np.array([g.shape for g in gs], np.int32), grid_data=np.concatenate([g.reshape(-1) for g in gs]))
         if neq:
             host["Je"] = Je
         for name, a in host.items():

@@ -317,9 +317,8 @@ class SDF3D(Body3D):
 class SDFGrid3D(Body3D):
     """`sdf_physics/physics3d/bodies.py:763-775`: the SDF is a voxel grid ``sdf`` [n,n,n] over the body's unit cube
     (``scale`` maps it to world units).  Mesh: marching cubes of the grid itself at its own resolution; inertia from
-    the mesh; queries through dss_grid_sdf_query.  A grid body can be built, meshed and queried; the batched stepper
-    does not take grid bodies yet (World3D raises)."""
-    shape_type = None
+    the mesh; queries through dss_grid_sdf_query; inside the stepper the kernels interpolate the same grid (geom.h: SHAPE_GRID)."""
+    shape_type = abi.SHAPE_GRID
 
     def __init__(self, pos, scale, sdf, vel=(0, 0, 0), mass=1, restitution=Defaults3D.RESTITUTION,
                  fric_coeff=Defaults3D.FRIC_COEFF, eps=Defaults3D.EPSILON, **kw):
@@ -336,7 +335,10 @@ class SDFGrid3D(Body3D):
     faces = property(lambda self: torch.as_tensor(self.faces_np))
 
     def shape_prm(self):
-        raise NotImplementedError("SDFGrid3D bodies are not part of the batched stepper yet")
+        return torch.zeros(3, dtype=torch.float64)      # the shape is the grid itself (World3D hands it to the engine)
+
+    def shape_aux(self):
+        return float(self.scale.detach())
 
     def query_sdfs(self, pts_loc, return_grads=True, return_overlapmask=False):
         return mass_properties.grid_sdf_query(self.sdf, float(self.scale.detach()), pts_loc, return_grads, return_overlapmask)

@@ -166,8 +166,6 @@ class World3D(BatchWorld3D):
         self.engine_plugin = engine() if isinstance(engine, type) else getattr(engines_module, engine)()
         self.bodies = bodies
         self.vec_len = 6
-        if any(b.shape_type is None for b in bodies):
-            raise NotImplementedError("SDFGrid3D bodies can be built, meshed and queried, but are not in the batched stepper yet")
         nb = len(bodies)
         idx = {id(b): i for i, b in enumerate(bodies)}
         rows = []
@@ -202,6 +200,10 @@ class World3D(BatchWorld3D):
                     shape_aux=np.array([[b.shape_aux() for b in bodies]], np.float64),
                     mesh_id=np.arange(nb, dtype=np.int32)[None], meshes=[(b.verts_np, b.faces_np) for b in bodies],
                     mesh_vgrad=[b.vgrad_np for b in bodies], Je=Je, no_contact=nocon)
+        grids = [b for b in bodies if b.shape_type == abi.SHAPE_GRID]
+        if grids:
+            spec["grids"] = [b.sdf.detach().cpu().numpy() for b in grids]
+            spec["grid_id"] = np.array([[grids.index(b) if b in grids else -1 for b in bodies]], np.int32)
         nets = {id(b.igr): b.igr for b in bodies if getattr(b, "igr", None) is not None}
         if len(nets) > 1:
             raise NotImplementedError("all neural SDF bodies of a world share one network (one decode_igr(network))")

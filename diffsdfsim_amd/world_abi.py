@@ -9,7 +9,7 @@ import numpy as np
 
 CAND_FIELDS = 28
 N_ACTIVE_OVERFLOW = 1 << 30
-SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_BOX_ROUNDED, SHAPE_BRICK, SHAPE_BOWL, SHAPE_IGR = 0, 1, 2, 3, 4, 5, 6
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_BOX_ROUNDED, SHAPE_BRICK, SHAPE_BOWL, SHAPE_IGR, SHAPE_GRID = 0, 1, 2, 3, 4, 5, 6, 7
 
 _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
@@ -21,6 +21,7 @@ FIELDS = [
     ("pose", "pd"), ("vel", "pd"),
     ("mass", "pd"), ("inertia", "pd"), ("restitution", "pd"), ("fric", "pd"), ("fext", "pd"),
     ("shape_type", "pi"), ("shape_prm", "pd"), ("shape_aux", "pd"), ("mesh_id", "pi"), ("no_contact", "pb"),
+    ("grid_id", "pi"), ("grid_off", "pi"), ("grid_dims", "pi"), ("grid_data", "pd"),
     ("mesh_voff", "pi"), ("mesh_nv", "pi"), ("mesh_foff", "pi"), ("mesh_nf", "pi"),
     ("verts", "pd"), ("faces", "pi"), ("fcent", "pd"), ("frad", "pd"), ("vgrad", "pd"),
     ("fch_box", "pd"), ("vch_box", "pd"), ("mesh_fch_off", "pi"), ("mesh_vch_off", "pi"),

@@ -136,6 +136,10 @@ typedef struct DssWorld {
     const double *shape_aux;    /* [B][nb]: corner radius r of a rounded box / brick (a constant, not differentiated) */
     const int *mesh_id;
     const unsigned char *no_contact; /* [nb][nb], shared by all scenes */
+    /* voxel-grid SDF bodies (DSS_SHAPE_GRID; SDFGrid3D, bodies.py:203-257, 763-775): shape_aux = scale, grid_id [B][nb] = the
+       body's grid in the pooled table (-1: none); grid g = doubles grid_data[grid_off[g] ..) of shape grid_dims[g][3], x slowest */
+    const int *grid_id, *grid_off, *grid_dims;
+    const double *grid_data;
     /* mesh table (body frame) */
     const int *mesh_voff, *mesh_nv, *mesh_foff, *mesh_nf;   /* [nmesh] */
     const double *verts;   /* [NV][3] */
@@ -241,6 +245,7 @@ typedef struct DssWorld {
 #define DSS_SHAPE_BOX_ROUNDED 3 /* SDFBoxRounded (bodies.py:857-870): shape_prm = outer dims, shape_aux = r */
 #define DSS_SHAPE_BRICK 4      /* SDFBrick (bodies.py:873-885): shape_prm = dims, shape_aux = r (x-y corners rounded) */
 #define DSS_SHAPE_BOWL 5       /* SDFBowl (bodies.py:1013-1027): shape_prm = (r, d, -), opening towards +z */
+#define DSS_SHAPE_GRID 7       /* SDFGrid3D (bodies.py:763-775): samples of the SDF over the body's unit cube, shape_aux = scale */
 #define DSS_SHAPE_IGR 6        /* SDF3D with decode_igr (bodies.py:627-760, utils.py:330-350): shape_prm = latent code (2), shape_aux = scale */
 #define DSS_IGR_HDR 16         /* ints of per-item state of the round-based narrow phase */
 #define DSS_IGR_ROUNDS 42      /* query rounds that cover every stage: candidates 2, Frank-Wolfe 1 + 31, projection 2, geometry 4, spare */

@@ -22,7 +22,7 @@ from oracle.gen import contact_record  # noqa: E402
 
 contact_record.install()
 from sdf_physics.physics3d.world import World3D  # noqa: E402
-from sdf_physics.physics3d.bodies import SDFBowl, SDFBox, SDFBoxRounded, SDFBrick, SDFCylinder, SDFSphere  # noqa: E402
+from sdf_physics.physics3d.bodies import SDFBowl, SDFBox, SDFBoxRounded, SDFBrick, SDFCylinder, SDFGrid3D, SDFSphere  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 MAXC = 160
@@ -41,7 +41,7 @@ def contacts_arrays(contacts):
 def describe(bodies, g=10.0, store_mesh=True):
     d = {}
     nb = len(bodies)
-    code = {SDFBox: 0, SDFSphere: 1, SDFCylinder: 2, SDFBoxRounded: 3, SDFBrick: 4, SDFBowl: 5}
+    code = {SDFBox: 0, SDFSphere: 1, SDFCylinder: 2, SDFBoxRounded: 3, SDFBrick: 4, SDFBowl: 5, SDFGrid3D: 7}
     d["shape_type"] = np.array([code[type(b)] for b in bodies], np.int32)
     prm, aux = np.zeros((nb, 3)), np.zeros(nb)
     for i, b in enumerate(bodies):
@@ -52,6 +52,9 @@ def describe(bodies, g=10.0, store_mesh=True):
             prm[i, 0], prm[i, 1] = float(b.r), float(b.d)
         elif isinstance(b, SDFCylinder):
             prm[i, 0], prm[i, 1] = float(b.rad), float(b.height)
+        elif isinstance(b, SDFGrid3D):
+            aux[i] = float(b.scale)
+            d["grid_%d" % i] = b.sdf.detach().numpy()
         else:
             prm[i, 0] = float(b.rad)
     d["shape_prm"], d["shape_aux"] = prm, aux
@@ -177,6 +180,8 @@ CASES = {
     # strict_no_penetration=False, and a sphere too fast for any halving of dt to catch in the contact band: the escape of
     # world.py:345-347 (dt < dt/2^10: go on with the penetrating contacts, unthinned, no time-of-contact bookkeeping)
     "rollout_fast_sphere": (lambda: scenes.fast_sphere(), dict(nsteps=3, strict_no_penetration=False)),
+    # a voxel-grid SDF body (SDFGrid3D): trilinear samples, central-difference normals; gradient w.r.t. its start velocity
+    "rollout_grid_body": (lambda: scenes.grid_body_drop(), dict(nsteps=12)),
 }
 
 

@@ -245,3 +245,20 @@ def fast_sphere(vy=-60.0, y0=1.2, rad=0.5, floor_dims=(4.0, 1.0, 4.0), mu=0.25, 
     ball = SDFSphere([0, y0, 0], rad_t, vel=[0, 0, 0, 0.3, vy, 0], custom_mesh=True, custom_inertia=True, restitution=rest, fric_coeff=mu)
     ball.add_force(Gravity3D())
     return [floor, ball], [TotalConstraint3D(floor)], [rad_t]
+
+
+def grid_body_drop(n=48, rad=0.5, scale=0.8, requires_grad=True):
+    """A voxel-grid SDF body (SDFGrid3D, bodies.py:763-775): the samples of a sphere's SDF (radius `rad` in the unit cube)
+    on n^3 points, dropped onto the floor with some spin and lateral speed.  The differentiable quantity is its start velocity
+    (a grid has no shape parameter)."""
+    from sdf_physics.physics3d.bodies import SDFBox, SDFGrid3D
+    from sdf_physics.physics3d.constraints import TotalConstraint3D
+    from sdf_physics.physics3d.forces import Gravity3D
+    g = torch.linspace(-1.0, 1.0, n, dtype=torch.double)
+    X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
+    sdf = torch.sqrt(X * X + Y * Y + Z * Z) - rad
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True, restitution=0.3, fric_coeff=0.4)
+    vel = torch.tensor([0.0, 0.0, 0.8, 0.5, -0.6, 0.0], dtype=torch.double, requires_grad=requires_grad)
+    body = SDFGrid3D([0.0, rad * scale + 0.02, 0.0], scale, sdf, vel=vel, restitution=0.3, fric_coeff=0.4)
+    body.add_force(Gravity3D())
+    return [floor, body], [TotalConstraint3D(floor)], [vel]

@@ -18,7 +18,10 @@ def marching_cubes(sdfs, iso):
     return torch.tensor(v, dtype=sdfs.dtype), torch.tensor(f, dtype=torch.int64)
 
 
+@torch.no_grad()
 def grid_interp(grid, inds):
+    """(A compiled extension function without an autograd formula: its result carries no graph -- the reference wraps the value
+    query in its own DiffGridSDF Function for that reason, bodies.py:244-257.)"""
     chan = grid.dim() == 4
     g = grid if chan else grid.unsqueeze(0)
     n = torch.tensor(g.shape[1:], dtype=torch.long)

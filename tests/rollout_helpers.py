@@ -22,6 +22,10 @@ def spec_from_golden(g, copies=1, level_set_mesh=None):
     extra = dict(shape_aux=rep(g["shape_aux"])) if "shape_aux" in g else {}
     if "no_contact" in g:
         extra["no_contact"] = np.asarray(g["no_contact"], np.uint8)
+    gb = [i for i in range(nb) if "grid_%d" % i in g]      # voxel-grid SDF bodies
+    if gb:
+        extra["grids"] = [g["grid_%d" % i] for i in gb]
+        extra["grid_id"] = rep(np.array([gb.index(i) if i in gb else -1 for i in range(nb)], np.int32))
     return dict(extra, pose=rep(g["pose0"]), vel=rep(g["vel0"]), mass=rep(g["mass"]), inertia=rep(g["inertia"]),
                 restitution=rep(g["restitution"]), fric=rep(g["fric"]), fext=rep(g["fext"]),
                 shape_type=rep(g["shape_type"]), shape_prm=rep(g["shape_prm"]), mesh_id=rep(np.arange(nb)),
@@ -160,7 +164,10 @@ def check_branches_and_pick_reference(E, g, s=0, margin=1e-9):
         else:
             ref_n, gb, gg = int(g["traj_nc"][j - 1]), g["traj_body"][j - 1], g["traj_geom"][j - 1]
             ref_st, ref_lap, ref_stB = g["traj_stable"][j - 1], g["traj_lap"][j - 1], (g["traj_stableB"][j - 1] if "traj_stableB" in g else None)
-        if n == 0 or n != ref_n:
+        if n != ref_n:
+            same["A"] = same["B"] = False      # another contact set: neither recorded run was reproduced step for step
+            continue
+        if n == 0:
             continue
         mine = contact_branches(face, n)
         # pair the build's contacts with the reference's by contact point (the order inside a body pair may differ)
