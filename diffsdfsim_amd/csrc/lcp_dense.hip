@@ -40,6 +40,14 @@ __host__ __device__ inline size_t ws_bytes_per_system(int nz, int nineq, int neq
     return (b + 255) & ~(size_t)255;
 }
 
+// staged vectors of a system (LDS), rounded to 16 bytes so that a workspace placed behind them stays aligned
+__host__ __device__ inline size_t lds_bytes(int nz, int nineq, int neq)
+{
+    return (size_t)((neq + nineq + 12 * nz + 4 * (neq + 1) + 8 + 1) & ~1) * sizeof(double);
+}
+// workspace in LDS when vectors + workspace fit this budget (five systems per CU at the limit)
+constexpr size_t WS_LDS_BUDGET = 30 * 1024;
+
 __device__ inline Ws carve(char *base, int nz, int nineq, int neq)
 {
     Ws w;
@@ -394,7 +402,7 @@ __global__ void __launch_bounds__(64)
 lcp_dense_forward_kernel(const double *Q, const double *p, const double *G, const double *h, const double *A,
                          const double *b, const double *F, int nz, int nineq, int neq, double eps,
                          int not_improved_lim, int max_iter, int check_spd, double *zhat, double *lam,
-                         double *slack, double *nu, int *iters, int *status, char *workspace, size_t ws_stride)
+                         double *slack, double *nu, int *iters, int *status, char *workspace, size_t ws_stride, int ws_in_lds)
 {
     DSS_DYN_LDS(double, lds);
     const int sys = blockIdx.x, lane = lane_id();
@@ -402,7 +410,9 @@ lcp_dense_forward_kernel(const double *Q, const double *p, const double *G, cons
     S.nz = nz; S.nineq = nineq; S.neq = neq;
     S.Q = Q + (size_t)sys * nz * nz; S.G = G + (size_t)sys * nineq * nz;
     S.A = neq ? A + (size_t)sys * neq * nz : nullptr; S.F = F + (size_t)sys * nineq * nineq;
-    S.w = carve(workspace + (size_t)sys * ws_stride, nz, nineq, neq);
+    // small systems keep the whole workspace in LDS behind the staged vectors (ws_in_lds: chosen by the launcher): a
+    // factorisation step is then an LDS round trip instead of an L2 / HBM one
+    S.w = carve(ws_in_lds ? reinterpret_cast<char *>(lds) + lds_bytes(nz, nineq, neq) : workspace + (size_t)sys * ws_stride, nz, nineq, neq);
     p += (size_t)sys * nz; h += (size_t)sys * nineq; if (neq) b += (size_t)sys * neq;
     zhat += (size_t)sys * nz; lam += (size_t)sys * nineq; slack += (size_t)sys * nineq; if (neq) nu += (size_t)sys * neq;
     Ws &w = S.w;
@@ -504,7 +514,7 @@ __global__ void __launch_bounds__(64)
 lcp_dense_backward_kernel(const double *Q, const double *G, const double *A, const double *F, int nz, int nineq,
                           int neq, const double *zhat, const double *lam, const double *slack, const double *nu,
                           const double *dl_dz, double *dQ, double *dp, double *dG, double *dh, double *dA,
-                          double *db, double *dF, char *workspace, size_t ws_stride)
+                          double *db, double *dF, char *workspace, size_t ws_stride, int ws_in_lds)
 {
     DSS_DYN_LDS(double, lds);
     const int sys = blockIdx.x, lane = lane_id();
@@ -512,7 +522,7 @@ lcp_dense_backward_kernel(const double *Q, const double *G, const double *A, con
     S.nz = nz; S.nineq = nineq; S.neq = neq;
     S.Q = Q + (size_t)sys * nz * nz; S.G = G + (size_t)sys * nineq * nz;
     S.A = neq ? A + (size_t)sys * neq * nz : nullptr; S.F = F + (size_t)sys * nineq * nineq;
-    S.w = carve(workspace + (size_t)sys * ws_stride, nz, nineq, neq);
+    S.w = carve(ws_in_lds ? reinterpret_cast<char *>(lds) + lds_bytes(nz, nineq, neq) : workspace + (size_t)sys * ws_stride, nz, nineq, neq);
     Ws &w = S.w;
     zhat += (size_t)sys * nz; lam += (size_t)sys * nineq; slack += (size_t)sys * nineq; dl_dz += (size_t)sys * nz;
     dQ += (size_t)sys * nz * nz; dp += (size_t)sys * nz; dG += (size_t)sys * nineq * nz; dh += (size_t)sys * nineq;
@@ -543,8 +553,6 @@ lcp_dense_backward_kernel(const double *Q, const double *G, const double *A, con
     }
 }
 
-inline size_t lds_bytes(int nz, int nineq, int neq) { return (size_t)(neq + nineq + 12 * nz + 4 * (neq + 1) + 8) * sizeof(double); }
-
 }  // namespace
 
 extern "C" {
@@ -567,11 +575,13 @@ int dss_lcp_dense_forward(const double *Q, const double *p, const double *G, con
     if (!Q || !p || !G || !h || !F || !zhat || !lam || !slack || !iters || !status || !workspace) return DSS_E_BADARG;
     if (neq > 0 && (!A || !b || !nu)) return DSS_E_BADARG;
     if (workspace_bytes < dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)) return DSS_E_WORKSPACE;
-    const size_t lds = lds_bytes(nz, nineq, neq);
+    size_t lds = lds_bytes(nz, nineq, neq);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
+    const int in_lds = lds + ws_bytes_per_system(nz, nineq, neq) <= WS_LDS_BUDGET;
+    if (in_lds) lds += ws_bytes_per_system(nz, nineq, neq);
     hipLaunchKernelGGL(lcp_dense_forward_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, Q, p, G, h, A, b, F,
                        nz, nineq, neq, eps, not_improved_lim, max_iter, check_spd, zhat, lam, slack, nu, iters,
-                       status, (char *)workspace, ws_bytes_per_system(nz, nineq, neq));
+                       status, (char *)workspace, ws_bytes_per_system(nz, nineq, neq), in_lds);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 
@@ -585,11 +595,13 @@ int dss_lcp_dense_backward(const double *Q, const double *G, const double *A, co
     if (!Q || !G || !F || !zhat || !lam || !slack || !dl_dz || !dQ || !dp || !dG || !dh || !dF || !workspace) return DSS_E_BADARG;
     if (neq > 0 && (!A || !nu || !dA || !db)) return DSS_E_BADARG;
     if (workspace_bytes < dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)) return DSS_E_WORKSPACE;
-    const size_t lds = lds_bytes(nz, nineq, neq);
+    size_t lds = lds_bytes(nz, nineq, neq);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
+    const int in_lds = lds + ws_bytes_per_system(nz, nineq, neq) <= WS_LDS_BUDGET;
+    if (in_lds) lds += ws_bytes_per_system(nz, nineq, neq);
     hipLaunchKernelGGL(lcp_dense_backward_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, Q, G, A, F, nz, nineq,
                        neq, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, dF, (char *)workspace,
-                       ws_bytes_per_system(nz, nineq, neq));
+                       ws_bytes_per_system(nz, nineq, neq), in_lds);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 
