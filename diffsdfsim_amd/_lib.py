@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libdiffsdfsim_hip.so")
+LIB_PATH = os.environ.get("DSS_LIB_PATH") or os.path.join(CSRC, "libdiffsdfsim_hip.so")    # (override: kernel experiments, tools/)
 _LIB = None
 
 ABI_VERSION = 1

@@ -340,6 +340,10 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return 0; }
     G::sync();
     STAMP(1);
+#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 1
+    if (tid == 0) *pc_count = 0;
+    return 0;
+#endif
 
     // ---- 2. Frank-Wolfe (contacts.py:57-82) -----------------------------------------------------
     // The first candidate of every thread lives in registers for the whole loop (typical pairs have fewer
@@ -496,6 +500,10 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     G::sync();
 
     STAMP(2);
+#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 2
+    if (tid == 0) *pc_count = 0;
+    return 0;
+#endif
     // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) -------------------
     double qrel[4];
     {
@@ -568,7 +576,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 #define DSS_NP_WAVES 3   // waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
 union NpScratch {
+#if !defined(DSS_NP_EXP_STOP)
     ScratchT<BlockGroup> blk;
+#endif
     ScratchT<WaveGroup> wav[BlockGroup::NW];
 };
 template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W_arg)
@@ -577,6 +587,7 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
     __shared__ NpScratch S;
     __shared__ int s_item;
     const int cap = W.B * npairs_of(W.nb), seg = DEFERRED ? 2 : 0;
+#if !defined(DSS_NP_EXP_STOP)
     {
         const int n = W.n_pairs[DEFERRED ? 4 : 0];
         const int *list = W.pair_list + (size_t)seg * cap;
@@ -589,6 +600,7 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
             narrow_pair<BlockGroup>(W, S.blk, list[it], (int)blockIdx.x * BlockGroup::NW);
         }
     }
+#endif
     if (DEFERRED) return;
     __syncthreads();   // nobody still reads the block scratch
     const int n = W.n_pairs[1], lane = threadIdx.x & 63;

@@ -121,7 +121,11 @@ template <int BT_, int HCAP_, int CHCAP_> struct Group {
     __device__ static inline int any(int x) { if (BT_ == 64) return __ballot(x) != 0ull; else return __syncthreads_or(x); }
 };
 using BlockGroup = Group<256, 1024, 704>;
+#if defined(DSS_NP_EXP_HCAP)
+using WaveGroup = Group<64, DSS_NP_EXP_HCAP, 32>;
+#else
 using WaveGroup = Group<64, 384, 32>;
+#endif
 
 template <class G> struct ScratchT {
     int wave_tot[G::NW];

@@ -4,6 +4,7 @@ The field order below IS the struct layout; ``dss_world_sizeof()`` is checked ag
 world is first bound to the library, so a mismatch fails loudly instead of corrupting memory.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -60,7 +61,7 @@ NP_DTYPE = {"pd": np.float64, "pi": np.int32, "pb": np.uint8}
 
 def np_slots(B, nb):
     """Scratch slots of the persistent narrow phase = wavefronts of its grid (mirrors dss_np_slots)."""
-    return 4 * min(B * nb * (nb - 1), 256 * 3)
+    return 4 * min(B * nb * (nb - 1), 256 * int(os.environ.get("DSS_NP_WAVES", 3)))     # (env: kernel experiments only)
 
 
 def igr_shapes(items_cap, qcap, max_cand):
