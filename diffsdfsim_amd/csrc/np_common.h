@@ -234,6 +234,155 @@ struct HullGlobal {
     __device__ inline void setf(int k, int v) const { cb[(size_t)6 * mc + k] = (double)v; }
 };
 
+
+#if DSS_ALL_SHAPES
+// ---- 3-D hull by gift wrapping (workgroup flavour, clusters beyond the brute-force limit) ----------------------------
+// A level-set body at rest on a side with a rounded rim gives one normal cluster of thousands of contact points -- the
+// resting face plus the first rows of the rim a fraction of a millimetre above it -- of which Qhull (contacts.py:126-152)
+// keeps the few dozen that are vertices of the 3-D hull.  Wrapping finds exactly those: around every directed hull edge
+// a -> b the next face is (a, b, c) with every point on or behind its plane.  Ties among points IN that plane (a facet
+// with hundreds of coplanar points) are broken like the 2-D wrap does it: the next vertex of the facet's polygon after b,
+// the farthest of collinear ones -- so the facet is fanned out over its polygon's vertices only and no interior or
+// mid-edge point ever becomes a vertex.  Coincident points are one vertex (the lowest index wins every tie).
+// Work per face: one pass over the points by the whole workgroup + an LDS tree; bookkeeping (the list of directed edges)
+// in the scan's LDS words, which are free by now.  Returns false (nothing flagged) if the wrap cannot be trusted: no
+// unique extreme start point in any of the probe directions, or more faces than the edge list holds.
+template <class P_> struct WrapEdge {
+    double a[3], e[3], le2;
+    int ia, ib;     // ia < 0: `a` is a virtual point (the start)
+};
+template <class P_> __device__ inline bool wrap_valid(const P_ &P, const WrapEdge<P_> &E, int c, double tolf)
+{
+    if (c == E.ia || c == E.ib) return false;
+    const double u[3] = {P.hp(c, 0) - E.a[0], P.hp(c, 1) - E.a[1], P.hp(c, 2) - E.a[2]};
+    double m[3];
+    cross(E.e, u, m);
+    return m[0] * m[0] + m[1] * m[1] + m[2] * m[2] > tolf * tolf * E.le2;      // off the edge's line (and off a and b)
+}
+// does candidate c2 take the place of c1 (both valid)
+template <class P_> __device__ inline bool wrap_better(const P_ &P, const WrapEdge<P_> &E, int c1, int c2, double tolf, double dtol2)
+{
+    if (c2 < 0) return false;
+    if (c1 < 0) return true;
+    const double u1[3] = {P.hp(c1, 0) - E.a[0], P.hp(c1, 1) - E.a[1], P.hp(c1, 2) - E.a[2]};
+    const double u2[3] = {P.hp(c2, 0) - E.a[0], P.hp(c2, 1) - E.a[1], P.hp(c2, 2) - E.a[2]};
+    double m1[3];
+    cross(E.e, u1, m1);
+    const double lm = sqrt(m1[0] * m1[0] + m1[1] * m1[1] + m1[2] * m1[2]);
+    const double s = (m1[0] * u2[0] + m1[1] * u2[1] + m1[2] * u2[2]) / lm;      // c2 above (+) / below the plane (a, b, c1)
+    if (s > tolf) return true;
+    if (s < -tolf) return false;
+    // in the plane: seen from outside the facet's polygon runs counter-clockwise, a -> b -> c with every point left of b -> c
+    const double v1[3] = {u1[0] - E.e[0], u1[1] - E.e[1], u1[2] - E.e[2]}, v2[3] = {u2[0] - E.e[0], u2[1] - E.e[1], u2[2] - E.e[2]};
+    double x[3];
+    cross(v1, v2, x);
+    const double cr = (x[0] * m1[0] + x[1] * m1[1] + x[2] * m1[2]) / lm;
+    const double lb = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], lq = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    const double c2s = cr * cr, t2 = dtol2 * fmax(lb, lq);     // the 2-D wrap's (Qhull's) measure of "collinear"
+    if (cr < 0.0 && c2s > t2) return true;
+    if (c2s <= t2) return lq > lb || (lq == lb && c2 < c1);
+    return false;
+}
+template <class G, class P_> __device__ int wrap_next(ScratchT<G> &S, const P_ &P, const WrapEdge<P_> &E, int m, double tolf, double dtol2)
+{
+    const int tid = G::tid();
+    int best = -1;
+    for (int k = tid; k < m; k += G::BT)
+        if (wrap_valid(P, E, k, tolf) && wrap_better(P, E, best, k, tolf, dtol2)) best = k;
+    S.red_i[tid] = best;
+    G::sync();
+    for (int s = G::BT / 2; s > 0; s >>= 1) {
+        if (tid < s) { const int a = S.red_i[tid], b = S.red_i[tid + s]; if (wrap_better(P, E, a, b, tolf, dtol2)) S.red_i[tid] = b; }
+        G::sync();
+    }
+    const int r = S.red_i[0];
+    G::sync();
+    return r;
+}
+template <class G, class P_> __device__ bool hull3_wrap(ScratchT<G> &S, const P_ &P, int m, double amax, double tolf, double dtol2)
+{
+    constexpr int EMAX = (G::CHCAP * 4) / 3;       // directed edges the list holds (three int arrays in S.woff)
+    if (EMAX < 96) return false;
+    const int tid = G::tid();
+    int *eu = S.woff, *ev = S.woff + EMAX, *est = S.woff + 2 * EMAX;     // est: 0 = needs its face, 1 = has it
+    // a start vertex: the extreme point of a direction in which it is the only one (no facet or edge perpendicular to it)
+    const double probes[3][3] = {{0.5411961001, 0.6363961031, 0.4209517757}, {-0.3826834324, 0.5879378012, 0.7126966451},
+                                 {0.7071067812, -0.4539904997, 0.5420261274}};
+    int i0 = -1;
+    double gdir[3] = {0, 0, 0};
+    for (int t = 0; t < 3 && i0 < 0; ++t) {
+        const double *g = probes[t];
+        double key = INFINITY; int ki = -1;
+        for (int k = tid; k < m; k += G::BT) {
+            const double v = g[0] * P.hp(k, 0) + g[1] * P.hp(k, 1) + g[2] * P.hp(k, 2);
+            if (v < key) { key = v; ki = k; }
+        }
+        const int c = block_argmin(key, ki, S);
+        const double vmin = g[0] * P.hp(c, 0) + g[1] * P.hp(c, 1) + g[2] * P.hp(c, 2);
+        int other = 0;
+        for (int k = tid; k < m; k += G::BT) {
+            const double v = g[0] * P.hp(k, 0) + g[1] * P.hp(k, 1) + g[2] * P.hp(k, 2);
+            const double d0 = P.hp(k, 0) - P.hp(c, 0), d1 = P.hp(k, 1) - P.hp(c, 1), d2 = P.hp(k, 2) - P.hp(c, 2);
+            other |= (v <= vmin + tolf) && (d0 * d0 + d1 * d1 + d2 * d2 > tolf * tolf);
+        }
+        if (!G::any(other)) { i0 = c; for (int d = 0; d < 3; ++d) gdir[d] = g[d]; }
+    }
+    if (i0 < 0) return false;
+    // first edge: wrap around a virtual line through the start vertex inside its supporting plane
+    WrapEdge<P_> E;
+    {
+        const double ex[3] = {1.0, 0.0, 0.0};
+        double d[3];
+        cross(gdir, ex, d);
+        const double ld = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), L = 1.0 + amax;
+        for (int k = 0; k < 3; ++k) { E.e[k] = d[k] / ld * L; E.a[k] = P.hp(i0, k) - E.e[k]; }
+        E.le2 = L * L; E.ia = -1; E.ib = i0;
+    }
+    const int i1 = wrap_next(S, P, E, m, tolf, dtol2);
+    if (i1 < 0) return false;
+    if (tid == 0) { eu[0] = i0; ev[0] = i1; est[0] = 0; eu[1] = i1; ev[1] = i0; est[1] = 0; P.setf(i0, 1); P.setf(i1, 1); S.wave_tot[0] = 2; }
+    G::sync();
+    int ne = 2;
+    for (int q = 0; q < ne; ++q) {
+        if (est[q]) continue;           // (uniform: LDS word read by every thread)
+        const int u = eu[q], v = ev[q];
+        for (int k = 0; k < 3; ++k) { E.a[k] = P.hp(u, k); E.e[k] = P.hp(v, k) - E.a[k]; }
+        E.le2 = E.e[0] * E.e[0] + E.e[1] * E.e[1] + E.e[2] * E.e[2]; E.ia = u; E.ib = v;
+        const int w = wrap_next(S, P, E, m, tolf, dtol2);
+        if (w < 0) return false;
+        // the face (u, v, w): its directed edges have their face now, their reverses need one unless they have it already
+        if (tid < 4) S.red_i[tid] = -1;
+        G::sync();
+        for (int e = tid; e < ne; e += G::BT) {
+            const int a = eu[e], b = ev[e];
+            if (a == v && b == w) S.red_i[0] = e;
+            if (a == w && b == u) S.red_i[1] = e;
+            if (a == w && b == v) S.red_i[2] = e;
+            if (a == u && b == w) S.red_i[3] = e;
+        }
+        G::sync();
+        if (tid == 0) {
+            int n2 = ne;
+            est[q] = 1;
+            auto put = [&](int slot, int a, int b, int state) {
+                const int e = S.red_i[slot];
+                if (e >= 0) { if (state) est[e] = 1; return; }
+                if (n2 < EMAX) { eu[n2] = a; ev[n2] = b; est[n2] = state; }
+                ++n2;
+            };
+            put(0, v, w, 1); put(1, w, u, 1); put(2, w, v, 0); put(3, u, w, 0);
+            P.setf(w, 1);
+            S.wave_tot[0] = n2;
+        }
+        G::sync();
+        ne = S.wave_tot[0];
+        G::sync();
+        if (ne > EMAX) return false;
+    }
+    return true;
+}
+#endif
+
 template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
 {
     const int tid = G::tid();
@@ -306,6 +455,14 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         }
     }
 #if DSS_HULL_EXACT
+#if DSS_ALL_SHAPES
+    // workgroup flavour, more points than the pairwise duplicate search below is meant for: gift wrapping
+    if (!flat3 && G::BT != 64 && m > 2048) {
+        if (hull3_wrap(S, P, m, amax, tolf, dtol2)) return;
+        for (int k = tid; k < m; k += G::BT) P.setf(k, 0);      // could not be trusted: every point is kept (below)
+        G::sync();
+    }
+#endif
     if (!flat3 && m > 2048) {   // beyond what the pairwise duplicate search below is meant for: keep every point
         for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
         G::sync();
@@ -346,6 +503,15 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             G::sync();
             const bool thin = listed || (G::BT == 64 && mu <= 512);
             const int nu = listed ? mu : m;
+            if (!thin && G::BT != 64) {      // more distinct points than the segment filter takes: the real hull
+                if (hull3_wrap(S, P, m, amax, tolf, dtol2)) {
+                    for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
+                    G::sync();
+                    return;
+                }
+                for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 1) P.setf(k, 0);
+                G::sync();
+            }
 #else
             const bool thin = false, listed = false;
             const int nu = m;

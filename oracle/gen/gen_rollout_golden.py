@@ -176,6 +176,8 @@ CASES = {
     "rollout_levelset_sphere": (lambda: scenes.levelset_sphere(), dict(nsteps=12, store_mesh=False)),
     "rollout_levelset_cylinder": (lambda: scenes.levelset_cylinder(), dict(nsteps=8, store_mesh=False)),
     "rollout_levelset_box": (lambda: scenes.levelset_box(), dict(nsteps=3, store_mesh=False)),
+    # level-set rounded box at rest on a rounded-rimmed side: a true 3-D hull of thousands of nearly coplanar points
+    "rollout_rounded_rest": (lambda: scenes.rounded_rest(), dict(nsteps=4, store_mesh=False)),
     "rollout_brick": (lambda: scenes.rounded_drop("brick"), dict(nsteps=10, store_mesh=False)),
     # strict_no_penetration=False, and a sphere too fast for any halving of dt to catch in the contact band: the escape of
     # world.py:345-347 (dt < dt/2^10: go on with the penetrating contacts, unthinned, no time-of-contact bookkeeping)

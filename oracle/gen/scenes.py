@@ -213,6 +213,18 @@ def levelset_box(mu=0.4, rest=0.1, requires_grad=False):
     return [f, b], [TotalConstraint3D(f)], ([d] if requires_grad else [])
 
 
+def rounded_rest(mu=0.4, rest=0.1):
+    """A level-set rounded box set down flat on the floor: one normal cluster of several thousand contact points that is
+    almost, but not quite, flat (the resting face plus the first rows of its rounded rim) -- Qhull's 3-D hull keeps a
+    few dozen of them."""
+    from sdf_physics.physics3d.bodies import SDFBoxRounded
+    SDFBox, SDFCylinder, SDFSphere, TotalConstraint3D, Gravity3D = _imports()
+    f = _floor(mu, rest)
+    b = SDFBoxRounded([0.0, 0.2 + 5e-4, 0.0], _T([0.8, 0.4, 0.7]), 0.1, vel=[0, 0.3, 0, 0.4, 0, 0.1], restitution=rest, fric_coeff=mu)
+    b.add_force(Gravity3D())
+    return [f, b], [TotalConstraint3D(f)], []
+
+
 def levelset_sphere(requires_grad=True):
     """A sphere with the reference's default (level-set) mesh and integrated inertia dropped with spin: gradient w.r.t. its
     radius through the SDF, the mesh scale and the inertia."""

@@ -181,6 +181,27 @@ def test_box_with_the_reference_default_mesh_resting_flat_matches_reference():
         R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
 
 
+def test_level_set_rounded_box_at_rest_on_its_rounded_rimmed_side_matches_reference():
+    """SDFBoxRounded (level-set mesh) set down flat: one normal cluster of several thousand contact points -- the resting
+    face and, a fraction of a millimetre above it, the first rows of the rounded rim -- that is neither flat nor small.
+    Qhull's 3-D hull (contacts.py:126-152) keeps 24-25 of them; the thinning stage gift-wraps that hull (np_common.h
+    `hull3_wrap`) and must arrive at the same contacts in every step, with no capacity error."""
+    from diffsdfsim_amd.engine import BatchEngine
+    g = R.load_rollout("rollout_rounded_rest")
+    E = BatchEngine(R.spec_from_golden(g, 2, level_set_mesh(g)), **R.engine_kwargs(g, max_sub=16, maxc=64, max_cand=32768, max_pc=48))
+    assert int(E.get("nc")[0]) == len(g["init_body"]), (int(E.get("nc")[0]), len(g["init_body"]))
+    for _ in range(4):
+        E.step()
+    assert int(E.get("overflow").max()) == 0 and (E.get("nsub") == len(g["traj_t"])).all()
+    assert int(E.get("pc_stats")[0].reshape(-1, 2)[:, 1].max()) > 3000      # thousands of candidates in one pair
+    k = len(g["traj_t"]) - 1
+    tnc = E.get("tp_nc")
+    assert [int(tnc[j, 0]) for j in range(1, k + 1)] == [int(g["traj_nc"][j - 1]) for j in range(1, k + 1)]
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
+    for s in (0, 1):
+        R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
+
+
 @pytest.mark.parametrize("name", ["rollout_levelset_sphere", "rollout_levelset_cylinder"])
 def test_default_mesh_sphere_and_cylinder_trajectory_and_gradient(name):
     """SDFSphere / SDFCylinder with the reference's defaults (custom_mesh = custom_inertia = False) through the class API:
