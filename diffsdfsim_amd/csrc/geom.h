@@ -204,6 +204,22 @@ template <class T> __host__ __device__ inline void quat_apply(const T *q, const 
     quat_raw_mul(t, qi, r);
     o[0] = r[1]; o[1] = r[2]; o[2] = r[3];
 }
+// The same for plain doubles with the zero real part of (0, p) folded away: a0 * 0 and "+ 0" drop out of quat_raw_mul's
+// left-to-right sums without changing any other bit (0 - x = -x and x + 0 = x exactly; only the sign of an exact zero can
+// differ, which nothing downstream looks at), and the real part of the second product is never formed.  12 multiplies and
+// 7 additions fewer per call, in the most frequent operation of the narrow phase.
+__host__ __device__ inline void quat_apply(const double *q, const double *p, double *o)
+{
+    const double tw = -q[1] * p[0] - q[2] * p[1] - q[3] * p[2];
+    const double tx = q[0] * p[0] + q[2] * p[2] - q[3] * p[1];
+    const double ty = q[0] * p[1] - q[1] * p[2] + q[3] * p[0];
+    const double tz = q[0] * p[2] + q[1] * p[1] - q[2] * p[0];
+    const double i0 = q[0], i1 = -q[1], i2 = -q[2], i3 = -q[3];      // q^-1
+    const double ox = tw * i1 + tx * i0 + ty * i3 - tz * i2;
+    const double oy = tw * i2 - tx * i3 + ty * i0 + tz * i1;
+    const double oz = tw * i3 + tx * i2 - ty * i1 + tz * i0;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+}
 template <class T> __host__ __device__ inline void quat_apply_inv(const T *q, const T *p, T *o)
 {
     T qi[4];

@@ -198,11 +198,18 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         return fabs(cb2[0]) <= lim && fabs(cb2[1]) <= lim && fabs(cb2[2]) <= lim;
     };
     // the reference's candidate test (contacts.py:44-52) in its own order of operations
-    auto full_face = [&](int f, double pqr[3][3]) -> int {
+    // (split in two so that the loads of two faces can be in flight before either is tested)
+    auto load_tri = [&](int f, double tri[3][3]) {
         const int *fv = m_faces + (size_t)(A.foff + f) * 3;
+        for (int k = 0; k < 3; ++k) {
+            const double *vp = m_verts + (size_t)(A.voff + fv[k]) * 3;
+            for (int i = 0; i < 3; ++i) tri[k][i] = vp[i];
+        }
+    };
+    auto test_tri = [&](double tri[3][3], double pqr[3][3]) -> int {
         double x[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) {
-            to_frame(A.g, Bd.g, m_verts + (size_t)(A.voff + fv[k]) * 3, pqr[k]);
+            to_frame(A.g, Bd.g, tri[k], pqr[k]);
             for (int i = 0; i < 3; ++i) x[i] += pqr[k][i];
         }
         div3(x, 3.0, x);   // the three exact quotients by one denominator (geom.h)
@@ -221,9 +228,20 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         const double gn = t_sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         return (phi < rad + W.eps) && (gn > 1e-12);
     };
+    auto full_face = [&](int f, double pqr[3][3]) -> int {
+        double tri[3][3];
+        load_tri(f, tri);
+        return test_tri(tri, pqr);
+    };
     auto test_face = [&](int f, double pqr[3][3]) -> int {
         return cull_face(m_fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
     };
+#if defined(DSS_NP_SCAN_STAMPS)
+#define SSTAMP(i) STAMP(i)
+#else
+#define SSTAMP(i)
+#endif
+    SSTAMP(1);
     if (G::BT == 64) {
         // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
         // flight, survivors packed in ascending order into LDS; (b) the full test on dense lanes.
@@ -236,19 +254,32 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         }
         if (npass > G::HCAP) return 1;   // more runs in reach than the wavefront's list holds: a workgroup takes the item
         G::sync();
+        SSTAMP(2);
         int *surv = reinterpret_cast<int *>(S.hp);
         constexpr int SCAP = (int)(sizeof(S.hp) / sizeof(int)) - 4 * 64;
         int nsurv = 0;
         auto flush = [&]() {
             G::sync();
-            for (int base = 0; base < nsurv; base += 64) {
-                const int f = base + lane < nsurv ? surv[base + lane] : -1;
-                double pqr[3][3];
-                const int flag = f >= 0 ? full_face(f, pqr) : 0;
-                const int slot = compact_slot(flag, ncand, S);
-                if (slot >= 0 && slot < MC) {
-                    cface[slot] = f;
-                    for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slot) = pqr[k][i2];
+            // two tiles of 64 survivors per round: the vertex loads of both are issued before either is tested (every
+            // round of this loop is a chain of two dependent global loads, and nothing else hides them)
+            for (int base = 0; base < nsurv; base += 128) {
+                const int vA = base + lane < nsurv, vB = base + 64 + lane < nsurv;
+                const int fA = vA ? surv[base + lane] : 0, fB = vB ? surv[base + 64 + lane] : 0;
+                double triA[3][3], triB[3][3], pqr[3][3];
+                load_tri(fA, triA);
+                load_tri(fB, triB);
+                const int flagA = test_tri(triA, pqr) && vA;
+                const int slotA = compact_slot(flagA, ncand, S);
+                if (slotA >= 0 && slotA < MC) {
+                    cface[slotA] = fA;
+                    for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slotA) = pqr[k][i2];
+                }
+                if (base + 64 >= nsurv) break;
+                const int flagB = test_tri(triB, pqr) && vB;
+                const int slotB = compact_slot(flagB, ncand, S);
+                if (slotB >= 0 && slotB < MC) {
+                    cface[slotB] = fB;
+                    for (int k = 0; k < 3; ++k) for (int i2 = 0; i2 < 3; ++i2) CB(3 * k + i2, slotB) = pqr[k][i2];
                 }
             }
             G::sync();
@@ -268,7 +299,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             }
             if (nsurv > SCAP) flush();
         }
+        SSTAMP(3);
         if (nsurv > 0) flush();
+        SSTAMP(4);
         if (ncand > MC) { over |= 1; ncand = MC; }
         if (tid == 0) { W.pc_stats[((size_t)sc * np + dp) * 2] = npass; W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = ncand; }
         G::sync();
@@ -339,7 +372,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     }
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return 0; }
     G::sync();
+#if !defined(DSS_NP_SCAN_STAMPS)
     STAMP(1);
+#endif
 #if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 1
     if (tid == 0) *pc_count = 0;
     return 0;
@@ -539,6 +574,10 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     G::sync();
 
     STAMP(3);
+#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 3
+    if (tid == 0) *pc_count = 0;
+    return 0;
+#endif
     // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
     int bad = 0;
     for (int k = tid; k < ncon; k += G::BT) {
@@ -551,6 +590,8 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (!stable) kface[k] |= DSS_FACE_NORMAL1;     // which body's normal it is travels with the face id
         for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; CB(i, k) = p2[i]; }   // pqr (fields 0-8) is dead by now
         CB(24, k) = pen;
+        // filter state of the contact (np_filter_emit.inc, NP_PRESTATE): 255 = no usable normal
+        if (k < G::HCAP) S.cst[k] = t_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 1e-12 ? 0 : 255;
         if (!(pen <= W.tol)) bad = 1;
     }
     if (G::any(bad)) {
@@ -562,7 +603,13 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         return 0;
     }
 
+#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 4
+    if (tid == 0) *pc_count = 0;
+    return 0;
+#endif
+#define NP_PRESTATE 1
 #include "np_filter_emit.inc"
+#undef NP_PRESTATE
 #undef STAMP
 #undef CB
 }
