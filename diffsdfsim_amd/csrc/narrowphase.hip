@@ -539,25 +539,29 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     if (tid == 0) *pc_count = 0;
     return 0;
 #endif
-    // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) -------------------
+    // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) ...
     double qrel[4];
     {
         double qbi[4];
         quat_inv(Bd.g.q, qbi);
         quat_mul(qbi, A.g.q, qrel);
     }
-    int ncon = 0;
+    // ... and 4. the contact geometry of the survivors, in the same round: the triangle is in registers already and the
+    // barycentrics need not travel through the scratch (one global round trip per 64 candidates less); compaction in
+    // ascending candidate order as before.  The attempt is rejected on penetration (contacts.py:237-240).
+    int ncon = 0, bad = 0;
     for (int base = 0; base < ncand; base += G::BT) {
         const int k = base + tid;
-        int flag = 0;
-        double abc[3] = {0, 0, 0};
+        int flag = 0, kf = 0;
+        double abc[3] = {0, 0, 0}, n[3] = {0, 0, 0}, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0}, pen = 0.0;
         if (k < ncand) {
-            const int *fv = m_faces + (size_t)(A.foff + cface[k]) * 3;
-            double xb1[3] = {0, 0, 0};
+            const int f = cface[k];
+            const int *fv = m_faces + (size_t)(A.foff + f) * 3;
+            double tri[3][3], xb1[3] = {0, 0, 0};
             for (int v = 0; v < 3; ++v) {
                 abc[v] = CB(12 + v, k);
                 const double *vp = m_verts + (size_t)(A.voff + fv[v]) * 3;
-                for (int i = 0; i < 3; ++i) xb1[i] += vp[i] * abc[v];
+                for (int i = 0; i < 3; ++i) { tri[v][i] = vp[i]; xb1[i] += tri[v][i] * abc[v]; }
             }
             double phi1, g1[3], gr[3], x[3], phi2, g2[3];
             query_sdf(A.g.shape, xb1, phi1, g1, true);
@@ -565,10 +569,24 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             for (int i = 0; i < 3; ++i) x[i] = CB(9 + i, k) - phi1 * gr[i];
             query_sdf(Bd.g.shape, x, phi2, g2, false);
             flag = phi2 <= W.eps;
+            if (flag) {
+                int stable = -1;
+                contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen, &stable);
+                kf = stable ? f : (f | DSS_FACE_NORMAL1);     // which body's normal it is travels with the face id
+                if (!(pen <= W.tol)) bad = 1;
+            }
         }
         if (!G::any(flag)) continue;
         const int slot = compact_slot(flag, ncon, S);
-        if (slot >= 0) { kface[slot] = cface[k]; for (int i = 0; i < 3; ++i) CB(15 + i, slot) = abc[i]; }
+        if (slot >= 0) {
+            kface[slot] = kf;
+            for (int i = 0; i < 3; ++i) {   // (slot <= k: fields 0-8, pqr, and 15-24 of a slot are dead or unread by now)
+                CB(15 + i, slot) = abc[i]; CB(18 + i, slot) = n[i]; CB(21 + i, slot) = p1[i]; CB(i, slot) = p2[i];
+            }
+            CB(24, slot) = pen;
+            // filter state of the contact (np_filter_emit.inc, NP_PRESTATE): 255 = no usable normal
+            if (slot < G::HCAP) S.cst[slot] = t_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 1e-12 ? 0 : 255;
+        }
     }
     if (ncon == 0) { if (tid == 0) { *pc_count = 0; if (over) atomicOr(W.overflow + sc, over); } return 0; }
     G::sync();
@@ -578,22 +596,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     if (tid == 0) *pc_count = 0;
     return 0;
 #endif
-    // ---- 4. contact geometry for all of them; reject the attempt on penetration ------------------
-    int bad = 0;
-    for (int k = tid; k < ncon; k += G::BT) {
-        const int *fv = m_faces + (size_t)(A.foff + kface[k]) * 3;
-        double tri[3][3], n[3], p1[3], p2[3], pen;
-        for (int v = 0; v < 3; ++v) for (int i = 0; i < 3; ++i) tri[v][i] = m_verts[(size_t)(A.voff + fv[v]) * 3 + i];
-        const double abc[3] = {CB(15, k), CB(16, k), CB(17, k)};
-        int stable = -1;
-        contact_from_bary(A.g, Bd.g, tri, abc, 1e-3, n, p1, p2, pen, &stable);
-        if (!stable) kface[k] |= DSS_FACE_NORMAL1;     // which body's normal it is travels with the face id
-        for (int i = 0; i < 3; ++i) { CB(18 + i, k) = n[i]; CB(21 + i, k) = p1[i]; CB(i, k) = p2[i]; }   // pqr (fields 0-8) is dead by now
-        CB(24, k) = pen;
-        // filter state of the contact (np_filter_emit.inc, NP_PRESTATE): 255 = no usable normal
-        if (k < G::HCAP) S.cst[k] = t_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 1e-12 ? 0 : 255;
-        if (!(pen <= W.tol)) bad = 1;
-    }
     if (G::any(bad)) {
         if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
         // attempts that will be accepted all the same (decide_kernel: strict_no_penetration=False, dt < dt / 2^10) keep this
