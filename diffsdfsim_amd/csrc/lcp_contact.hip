@@ -325,7 +325,10 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
         };
         // batches of BATCH contacts regardless of where the (body1, body2) runs end; the run sum is flushed into K
         // whenever the pair changes (uniform branch), so the accumulation order stays the contact order
-        constexpr int BATCH = 8;
+#ifndef DSS_ASM_BATCH
+#define DSS_ASM_BATCH 2
+#endif
+        constexpr int BATCH = DSS_ASM_BATCH;
         int pb1 = -1, pb2 = -1;
         double acc[3] = {0.0, 0.0, 0.0};
         auto flush = [&]() {
@@ -341,8 +344,12 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             for (int u = 0; u < BATCH; ++u) rd(c + u, t[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
+#if defined(DSS_ASM_NOBRANCH)
+                if (pb1 < 0) { pb1 = cbody[0]; pb2 = cbody[L.maxc]; }
+#else
                 const int b1 = cbody[c + u], b2 = cbody[L.maxc + c + u];
                 if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
+#endif
                 double o[3];
                 term(t[u], o);
 #pragma unroll
@@ -940,7 +947,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
     LSTAMP(0);
     for (it = 0; it < max_iter; ++it) {
         // ---- residuals (batch.py:117-131), the affine right-hand side and K(d) ------------------
-        double acc_rz = 0.0, acc_sz = 0.0, Cv[CPL][9];
+        double acc_rz = 0.0, acc_sz = 0.0;
         const int l0 = opaque_lane(lane);
 #pragma unroll
         for (int r = 0; r < CPL; ++r) {
@@ -969,7 +976,6 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
             w_vec<ND>(g, u, w);
 #pragma unroll
             for (int j = 0; j < 3; ++j) L.cw[6 * c + 3 + j] = w[j];
-            c_mat<ND>(g, av[r], ag, Cv[r]);
         }
         acc_rz = wave_sum(acc_rz);
         const double sz = wave_sum(acc_sz);
@@ -1009,11 +1015,18 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
 
         // ---- K(d) and the affine direction (batch.py:135,174) --------------------------------
         __syncthreads();
+        // the contacts' C matrices, formed here rather than carried in registers (18 doubles per lane) through the gathers
+        // and the residual block above: the operands come from L2 again, the registers are what this kernel is short of
 #pragma unroll
         for (int r = 0; r < CPL; ++r)
-            if (valid[r])
+            if (valid[r]) {
+                Geo<ND> g;
+                load_geo<ND>(g, cop, cbody, maxc, l0 + WAVE * r);
+                double C[9];
+                c_mat<ND>(g, av[r], s[r][NR - 1] / z[r][NR - 1], C);
 #pragma unroll
-                for (int j = 0; j < 9; ++j) L.cw[9 * (l0 + WAVE * r) + j] = Cv[r][j];
+                for (int j = 0; j < 9; ++j) L.cw[9 * (l0 + WAVE * r) + j] = C[j];
+            }
         __syncthreads();
         LSTAMP(4);
         assemble_K(L, Mblk, A, cbody, nc);

@@ -6,7 +6,7 @@ import numpy as np, torch
 from diffsdfsim_amd import _lib, scenes
 src = sorted(glob.glob(os.path.join(_lib.CSRC, "*.hip")))
 diag = os.path.join(_lib.CSRC, "libdiffsdfsim_hip_diag.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DDSS_DIAG", "-o", diag] + src)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DDSS_DIAG", "-o", diag] + os.environ.get("DSS_DIAG_FLAGS", "").split() + src)
 _lib.LIB_PATH = diag
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend
 L0 = ctypes.CDLL(diag)
