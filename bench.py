@@ -292,12 +292,11 @@ def main():
             if sample:
                 igr_attempts.append((len(ev) - 1, len(igr_ms)))
                 qn = E.get("igr_qn")
-                for r in range(1, abi.IGR_ROUNDS + 1):
-                    for l in range(2):
-                        if qn[2 * r + l] > 0:
-                            igr_ms.append(igr_events[4 * r + 2 * l].elapsed_time(igr_events[4 * r + 2 * l + 1]))
-                            igr_pts.append((int(qn[2 * r + l]), l))
-                            igr_est.append(int(hint_was[2 * r + l]) if hint_was is not None else -1)
+                for r in range(1, abi.IGR_ROUNDS + 1):      # one launch per round serves the value and the gradient list
+                    if qn[2 * r] + qn[2 * r + 1] > 0:
+                        igr_ms.append(igr_events[4 * r].elapsed_time(igr_events[4 * r + 1]))
+                        igr_pts.append((int(qn[2 * r]), int(qn[2 * r + 1])))
+                        igr_est.append((int(hint_was[2 * r]), int(hint_was[2 * r + 1])) if hint_was is not None else (-1, -1))
             k += 1
         return k
 
@@ -376,26 +375,29 @@ def main():
     extra = {}
     if neural and igr_ms:
         ms = np.array(igr_ms)
-        flops = np.array([2.0 * IGR_MAC_PER_POINT * n * (4 if l == 1 else 1) for n, l in igr_pts])
+        flops = np.array([2.0 * IGR_MAC_PER_POINT * (nv_ + 4 * ng_) for nv_, ng_ in igr_pts])
         tot = qn_total.cpu().numpy()
         nv, ng = int(tot[2::2].sum()), int(tot[3::2].sum())
         ach = flops.sum() / (ms.sum() * 1e-3) / 1e12
         big = flops >= np.percentile(flops, 90)
-        r_igr = {"bound": "mfma", "kernel": "igr_query_kernel (fp64 v_mfma_f64_16x16x4)", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-                 "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic("igr_query_kernel"),
+        r_igr = {"bound": "mfma", "kernel": "igr_query2_kernel (fp64 v_mfma_f64_16x16x4)", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic("igr_query2_kernel"),
                  "avg_launch_ms": float(ms.mean()), "launches_sampled": len(ms),
                  "algorithmic_flops_per_launch": float(flops.mean()),
-                 "largest_decile_launches": {"TFLOPs": float(flops[big].sum() / (ms[big].sum() * 1e-3) / 1e12), "avg_points": float(np.mean([n for (n, l), b in zip(igr_pts, big) if b]))},
-                 "points_evaluated": {"value_only": nv, "with_gradient": ng, "per_step": (nv + ng) / K},
-                 "mfma_busy_frac": pmc_sum(pmc, "mfma_busy_frac", "igr_query_kernel"),
+                 "largest_decile_launches": {"TFLOPs": float(flops[big].sum() / (ms[big].sum() * 1e-3) / 1e12),
+                                             "avg_points_value_list": float(np.mean([a for (a, g_), b in zip(igr_pts, big) if b])),
+                                             "avg_points_gradient_list": float(np.mean([g_ for (a, g_), b in zip(igr_pts, big) if b]))},
+                 "points_evaluated": {"value_only": nv, "with_gradient": ng, "per_step": (nv + ng) / K,
+                                      "value_list_by_round": [int(x) for x in tot[2::2][:12]], "gradient_list_by_round": [int(x) for x in tot[3::2][:12]]},
+                 "mfma_busy_frac": pmc_sum(pmc, "mfma_busy_frac", "igr_query2_kernel"),
                  "sampled_attempts": {"detection_ms_mean": float(np.mean([det_ms[a] for a, _ in igr_attempts])),
                                       "network_ms_mean": float(ms.sum() / max(1, len(igr_attempts))),
                                       "detection_ms_all_attempts_mean": float(det_ms.mean())},
                  "detection_ms_first_attempts": [round(float(x), 2) for x in det_ms[:48]],
-                 "slowest_launches": [{"ms": float(ms[i]), "points": igr_pts[i][0], "list": "grad" if igr_pts[i][1] else "value", "hint": igr_est[i]}
+                 "slowest_launches": [{"ms": float(ms[i]), "points_value_list": igr_pts[i][0], "points_gradient_list": igr_pts[i][1], "hints": list(igr_est[i])}
                                       for i in np.argsort(-ms)[:6]],
-                 "note": "network evaluations of the neural narrow phase, one launch per query round and list; flops = 2 x 115456 MAC per "
-                         "point (x4 with the three xyz tangents); events around one attempt in %d" % IGR_EV_EVERY}
+                 "note": "network evaluations of the neural narrow phase, one launch per query round (value list + gradient list); flops = "
+                         "2 x 115456 MAC per point (x4 with the three xyz tangents); events around one attempt in %d" % IGR_EV_EVERY}
         dominant, other = r_igr, r_det
         extra["roofline_third_kernel"] = r_lcp
     else:

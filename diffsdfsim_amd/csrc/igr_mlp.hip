@@ -59,10 +59,11 @@ struct Query {
 
 // Wp: packed weights.  Per hidden->hidden layer (7 of them): [tile t 0..7][kstep 0..31][lane 0..63] = W[16t + (lane&15)][4ks + (lane>>4)]
 // NW waves per workgroup share the activations of NG row groups; wave w owns neuron tiles [w*8/NW, (w+1)*8/NW)
-template <int NW, int NG, int MODE> __global__ void __launch_bounds__(64 * NW)
-igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, const double *bh, const double *W8, const double *b8)
+// bid / nblk: this workgroup's place among the workgroups that walk Q's tiles (a launch may serve two lists, see below)
+template <int NW, int NG, int MODE> __device__ __forceinline__ void
+igr_body(const Query &Q, int bid, int nblk, double *X, const double *W0, const double *b0, const double *Wp, const double *bh,
+         const double *W8, const double *b8)
 {
-    DSS_DYN_LDS(double, X);   // [ROWS][LDX]; with tangents row = 16 g + 4*quantity + point, without row = point
     constexpr bool TAN = MODE != MODE_VALUE;
     constexpr int PTS = (TAN ? 4 : 16) * NG, ROWS = 16 * NG, NT = 64 * NW, TPW = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -71,7 +72,7 @@ igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, 
     // row of (point p of the tile, quantity) and back
     auto row_of = [](int p, int quant) { return TAN ? 16 * (p / 4) + 4 * quant + (p % 4) : p; };
 
-    for (int base = blockIdx.x * PTS; base < n; base += gridDim.x * PTS) {
+    for (int base = bid * PTS; base < n; base += nblk * PTS) {
         // ---- layer 0 (K = 5) on the vector ALU: h0 = softplus(W0 [latent, xyz] + b0), tangents = sigma' * W0[:, seed]
         for (int e = tid; e < PTS * H; e += NT) {
             const int p = e / H, j = e % H, gp = base + p;
@@ -181,6 +182,25 @@ igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, 
         __syncthreads();   // the next tile's layer 0 overwrites X
     }
 }
+template <int NW, int NG, int MODE> __global__ void __launch_bounds__(64 * NW)
+igr_query_kernel(Query Q, const double *W0, const double *b0, const double *Wp, const double *bh, const double *W8, const double *b8)
+{
+    DSS_DYN_LDS(double, X);   // [ROWS][LDX]; with tangents row = 16 g + 4*quantity + point, without row = point
+    igr_body<NW, NG, MODE>(Q, (int)blockIdx.x, (int)gridDim.x, X, W0, b0, Wp, bh, W8, b8);
+}
+// One launch for the two lists of a query round of the neural narrow phase: workgroups [0, split) walk the value list, the
+// rest the gradient list.  Both lists are short most of the time (a Frank-Wolfe round: a few points per item), so each on
+// its own is a launch whose duration is the latency of one tile through nine layers, with most of the chip idle -- and
+// there are 42 rounds per detection.
+template <int NW, int NG> __global__ void __launch_bounds__(64 * NW)
+igr_query2_kernel(Query Qv, Query Qg, int split, const double *W0, const double *b0, const double *Wp, const double *bh,
+                  const double *W8, const double *b8)
+{
+    DSS_DYN_LDS(double, X);
+    const int bid = (int)blockIdx.x;
+    if (bid < split) igr_body<NW, NG, MODE_VALUE>(Qv, bid, split, X, W0, b0, Wp, bh, W8, b8);
+    else igr_body<NW, NG, MODE_XYZ>(Qg, bid - split, (int)gridDim.x - split, X, W0, b0, Wp, bh, W8, b8);
+}
 
 template <int NW, int NG, int MODE>
 void launch(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t stream)
@@ -210,6 +230,27 @@ void launch(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t 
                        N.bh, N.W8, N.b8);
 }
 
+// workgroups for a device-length list of which `est` points are expected (see launch above)
+template <int PTS> inline long tiles_for(int n_cap, int est)
+{
+    long tiles = ((long)n_cap + PTS - 1) / PTS, want = est < 0 ? 512 : (2L * est + PTS - 1) / PTS + 2;
+    if (want < 128) want = 128;
+    tiles = want < tiles ? want : tiles;
+    if (tiles > 256L * 2 * 4) tiles = 256L * 2 * 4;
+    return tiles < 1 ? 1 : tiles;
+}
+template <int NW, int NG> void launch2(const Query &Qv, const Query &Qg, const DssIgrNet &N, int n_cap, int estv, int estg, hipStream_t stream)
+{
+    const size_t lds = (size_t)16 * NG * LDX * sizeof(double);
+#if !defined(DSS_EMU)
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)igr_query2_kernel<NW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+    const long tv = tiles_for<16 * NG>(n_cap, estv), tg = tiles_for<4 * NG>(n_cap, estg);
+    hipLaunchKernelGGL((igr_query2_kernel<NW, NG>), dim3((unsigned)(tv + tg)), dim3(64 * NW), lds, stream, Qv, Qg, (int)tv, N.W0, N.b0,
+                       N.Wp, N.bh, N.W8, N.b8);
+}
+
 template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t stream)
 {
     // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 4 row groups, which quarters
@@ -217,7 +258,11 @@ template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_c
     // workgroup, a quarter of the latency of a pass and four times as many workgroups to spread over the chip.
     // All variants give bit-identical results (a point's row never mixes with its tile-mates').
     const int n = Q.n_dev ? (est < 0 ? n_cap : est) : n_cap;
+#if defined(DSS_IGR_BIG_NW)      // (experiment builds: another variant for the big lists)
+    if (n >= 16 * 1024) launch<DSS_IGR_BIG_NW, DSS_IGR_BIG_NG, MODE>(Q, N, n_cap, est, stream);
+#else
     if (n >= 16 * 1024) launch<4, 4, MODE>(Q, N, n_cap, est, stream);
+#endif
     else if (n >= 2 * 1024) launch<2, 2, MODE>(Q, N, n_cap, est, stream);
     else launch<4, 1, MODE>(Q, N, n_cap, est, stream);
 }
@@ -235,6 +280,19 @@ int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, c
     if (mode == MODE_VALUE) launch_mode<MODE_VALUE>(Q, N, n_cap, est, stream);
     else if (mode == MODE_LATENT) launch_mode<MODE_LATENT>(Q, N, n_cap, est, stream);
     else launch_mode<MODE_XYZ>(Q, N, n_cap, est, stream);
+    return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
+}
+// the value list and the gradient list of one query round in one launch (both lengths in device memory)
+int launch_igr_pair(const DssIgrNet &N, const double *pts_v, const int *lat_v, const int *n_v, double *sdf_v, const double *pts_g,
+                    const int *lat_g, const int *n_g, double *sdf_g, double *grad_g, const double *latents, int lat_stride, int n_cap,
+                    hipStream_t stream, int est_v, int est_g)
+{
+    Query Qv{pts_v, lat_v, latents, lat_stride, n_v, n_cap, sdf_v, nullptr}, Qg{pts_g, lat_g, latents, lat_stride, n_g, n_cap, sdf_g, grad_g};
+    // variant by the work expected (a gradient point is four rows): see launch_mode
+    const long rows = (est_v < 0 || est_g < 0) ? (long)n_cap : (long)est_v + 4L * est_g;
+    if (rows >= 16 * 1024) launch2<4, 4>(Qv, Qg, N, n_cap, est_v, est_g, stream);
+    else if (rows >= 2 * 1024) launch2<2, 2>(Qv, Qg, N, n_cap, est_v, est_g, stream);
+    else launch2<4, 1>(Qv, Qg, N, n_cap, est_v, est_g, stream);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 }  // namespace dss

@@ -27,8 +27,9 @@
 #include "np_common.h"
 
 namespace dss {
-int launch_igr_list(const DssIgrNet &N, const double *pts, const int *lat_idx, const double *latents, int lat_stride,
-                    const int *n_dev, int n_cap, int mode, double *sdf, double *grad, hipStream_t stream, int est);
+int launch_igr_pair(const DssIgrNet &N, const double *pts_v, const int *lat_v, const int *n_v, double *sdf_v, const double *pts_g,
+                    const int *lat_g, const int *n_g, double *sdf_g, double *grad_g, const double *latents, int lat_stride, int n_cap,
+                    hipStream_t stream, int est_v, int est_g);
 }
 
 namespace {
@@ -640,16 +641,16 @@ int launch_igr_rounds(const DssWorld &W, hipStream_t stream)
     if (W.igr_hint) { int want = 2 * W.igr_hint[0] + 8; if (want < 64) want = 64; if (want < grid) grid = want; }
     for (int r = 0; r <= rounds; ++r) {
         if (r > 0) {
+            // both lists of the round in ONE launch (igr_mlp.hip: igr_query2_kernel)
             const int set = r & 1;
-            for (int l = 0; l < 2; ++l) {
-                const size_t o = (size_t)(2 * set + l) * W.igr_qcap;
-                if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l], stream);
-                const int rc = launch_igr_list(W.igr, W.igr_qpts + o * 3, W.igr_qlat + o, W.shape_prm, 3, W.igr_qn + 2 * r + l, W.igr_qcap,
-                                               l == L_VALUE ? DSS_IGR_VALUE : DSS_IGR_XYZ, W.igr_qsdf + o,
-                                               W.igr_qgrad + (size_t)set * W.igr_qcap * 3, stream, W.igr_hint ? W.igr_hint[2 * r + l] : -1);
-                if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 2 * l + 1], stream);
-                if (rc) return rc;
-            }
+            const size_t ov = (size_t)(2 * set + L_VALUE) * W.igr_qcap, og = (size_t)(2 * set + L_GRAD) * W.igr_qcap;
+            if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r], stream);
+            const int rc = launch_igr_pair(W.igr, W.igr_qpts + ov * 3, W.igr_qlat + ov, W.igr_qn + 2 * r + L_VALUE, W.igr_qsdf + ov,
+                                           W.igr_qpts + og * 3, W.igr_qlat + og, W.igr_qn + 2 * r + L_GRAD, W.igr_qsdf + og,
+                                           W.igr_qgrad + (size_t)set * W.igr_qcap * 3, W.shape_prm, 3, W.igr_qcap, stream,
+                                           W.igr_hint ? W.igr_hint[2 * r + L_VALUE] : -1, W.igr_hint ? W.igr_hint[2 * r + L_GRAD] : -1);
+            if (W.igr_ev) (void)hipEventRecord((hipEvent_t)W.igr_ev[4 * r + 1], stream);
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(igr_advance_kernel, dim3(grid), dim3(G::BT), 0, stream, W, r, rounds);
     }
