@@ -71,11 +71,12 @@ __host__ __device__ inline void contact_head(const BodyG<T> &b1, const T tri[3][
 }
 template <class T>
 __host__ __device__ inline void contact_tail(const BodyG<T> &b1, const BodyG<T> &b2, const T *cp1, const T *n1, const T &d1,
-                                             const T *p1, double lap_h, T *n, T *p2, T &pen, int *stable_io)
+                                             const T *p1, double lap_h, T *n, T *p2, T &pen, int *stable_io, bool detach_b2 = false)
 {
     T cpw[3], rel[3], cp2[3], d2, n2[3], t[3];
     for (int i = 0; i < 3; ++i) { cpw[i] = p1[i] + b1.pos[i]; rel[i] = cpw[i] - b2.pos[i]; }
     quat_apply_inv(b2.q, rel, cp2);
+    if (detach_b2) for (int i = 0; i < 3; ++i) cp2[i] = T(val(cp2[i]));     // World3D(detach_contact_b2=True), contacts.py:175-178
 #if DSS_ALL_SHAPES
     if (b2.shape.type == SHAPE_IGR) igr_lin(b2.shape, 0, cp2, d2, n2);
     else
@@ -101,11 +102,11 @@ __host__ __device__ inline void contact_tail(const BodyG<T> &b1, const BodyG<T> 
 template <class T>
 __host__ __device__ inline void contact_from_bary(const BodyG<T> &b1, const BodyG<T> &b2, const T tri[3][3],
                                                   const double abc[3], double lap_h, T *n, T *p1, T *p2, T &pen,
-                                                  int *stable_io = nullptr)
+                                                  int *stable_io = nullptr, bool detach_b2 = false)
 {
     T cp1[3], n1[3], d1;
     contact_head(b1, tri, abc, cp1, n1, d1, p1);
-    contact_tail(b1, b2, cp1, n1, d1, p1, lap_h, n, p2, pen, stable_io);
+    contact_tail(b1, b2, cp1, n1, d1, p1, lap_h, n, p2, pen, stable_io, detach_b2);
 }
 
 // ---- time-of-contact distance function (World.H.D, lcp_physics/physics/world.py:150-174) composed with the

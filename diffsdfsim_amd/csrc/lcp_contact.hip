@@ -1204,8 +1204,10 @@ __global__ void __launch_bounds__(64)
 lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double *cop_, const int *cbody_,
                             const int *ncs, const int *active, int nb, int neq, int maxc, const double *x_, const double *lam_,
                             const double *slack_, const double *nu_, const double *dl_dx_, double *dMblk_,
-                            double *dpvec_, double *dcop_, double *dA_, double *db_)
+                            double *dpvec_, double *dcop_, double *dA_, double *db_, int rows)
 {
+    // rows: which rows of G pass gradient to the contact geometry they are built from -- 1 the normal row (Jc), 2 the
+    // friction rows (Jf); World3D's stop_contact_grad / stop_friction_grad build the others from detached geometry
     constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
     DSS_DYN_LDS(double, ldsmem);
     const int sc = blockIdx.x, lane = lane_id();
@@ -1283,14 +1285,21 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
         g_rows<ND>(g, vrx, r);
         w_apply<ND>(g.mu, a, fmax(slack[(size_t)(NR - 1) * maxc + c], 1e-8) / fmax(l[NR - 1], 1e-8), r, dl);  // dlam = W G dx
         // directions
+        const double mn = (rows & 1) ? 1.0 : 0.0, mf = (rows & 2) ? 1.0 : 0.0;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dcop[(size_t)j * maxc + c] = dl[0] * vrz[j] + l[0] * vrx[j];
+        for (int j = 0; j < 3; ++j) dcop[(size_t)j * maxc + c] = mn * (dl[0] * vrz[j] + l[0] * vrx[j]);
 #pragma unroll
         for (int k = 1; k <= ND; ++k)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                dcop[(size_t)(3 * k + j) * maxc + c] = (dl[k] - dl[ND + k]) * vrz[j] + (l[k] - l[ND + k]) * vrx[j];
-        // contact points
+                dcop[(size_t)(3 * k + j) * maxc + c] = mf * ((dl[k] - dl[ND + k]) * vrz[j] + (l[k] - l[ND + k]) * vrx[j]);
+        // contact points (through the rows that carry gradient)
+        const double dmu = dl[NR - 1] * l[0], dhn = -dl[0];
+        if (rows != 3) {
+            l[0] *= mn; dl[0] *= mn;
+#pragma unroll
+            for (int k = 1; k <= 2 * ND; ++k) { l[k] *= mf; dl[k] *= mf; }
+        }
         w_vec<ND>(g, l, wl);
         w_vec<ND>(g, dl, wdl);
         const int o = 3 * (1 + ND);
@@ -1302,11 +1311,19 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
         cross3(wl, dx + 6 * g.b2, t2);
 #pragma unroll
         for (int j = 0; j < 3; ++j) dcop[(size_t)(o + 3 + j) * maxc + c] = -(t1[j] + t2[j]);
-        dcop[(size_t)(o + 6) * maxc + c] = dl[NR - 1] * l[0];  // dF[cone_c, normal_c] = dlam_cone lam_n
-        dcop[(size_t)(o + 7) * maxc + c] = -dl[0];             // dh_n = -dlam_n
+        dcop[(size_t)(o + 6) * maxc + c] = dmu;   // dF[cone_c, normal_c] = dlam_cone lam_n
+        dcop[(size_t)(o + 7) * maxc + c] = dhn;   // dh_n = -dlam_n
     }
 }
 
+}  // namespace
+namespace dss {
+int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
+                              const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
+                              const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream);
+}
+namespace {
 inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
 {
     return B > 0 && nb > 0 && neq >= 0 && maxc > 0 && (fd == 4 || fd == 8);
@@ -1368,6 +1385,18 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
                              const double *slack, const double *nu, const double *dl_dx, double *dMblk,
                              double *dpvec, double *dcop, double *dA, double *db, void *stream)
 {
+    return dss::lcp_contact_backward_rows(Mblk, A, cop, cbody, nc, active, B, nb, neq, maxc, fric_dirs, x, lam, slack, nu, dl_dx, dMblk,
+                                          dpvec, dcop, dA, db, 3, stream);
+}
+
+}  // extern "C"
+
+namespace dss {
+int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
+                              const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
+                              const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream)
+{
     if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return DSS_E_BADARG;
     if (!Mblk || !cop || !cbody || !nc || !x || !lam || !slack || !dl_dx || !dMblk || !dpvec || !dcop) return DSS_E_BADARG;
     if (neq > 0 && (!A || !nu)) return DSS_E_BADARG;
@@ -1376,11 +1405,10 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_backward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows);
     else
         hipLaunchKernelGGL(lcp_contact_backward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
-
-}  // extern "C"
+}  // namespace dss

@@ -107,6 +107,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     constexpr int N = 4;
     typedef Dual<N> D;
     const int nb = W.nb;
+    const bool det2 = (W.grad_flags & DSS_GRAD_DETACH_B2) != 0;
     const double *P1 = pose_n + 7 * b1, *P2 = pose_n + 7 * b2;
     const double *prm1 = W.shape_prm + ((size_t)sc * nb + b1) * 3, *prm2 = W.shape_prm + ((size_t)sc * nb + b2) * 3;
     const int ty1 = W.shape_type[(size_t)sc * nb + b1], ty2 = W.shape_type[(size_t)sc * nb + b2];
@@ -174,7 +175,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
                 tri[v][i] = d;
             }
         D n[3], p1[3], p2[3], pen;
-        contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable);
+        contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable, det2);
         if (grp == 0) contract(n, p1, p2, 0, 4);
         else contract(n, p1, p2, 14, 3);
     }
@@ -197,7 +198,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
 #endif
         D cp1[3], n1[3], d1(d1v), p1[3], n[3], p2[3], pen;
         for (int i = 0; i < 3; ++i) { cp1[i] = D(cp1v[i]); n1[i] = D(n1v[i]); p1[i] = D(p1v[i]); }
-        contact_tail(B1, B2, cp1, n1, d1, p1, 1e-3, n, p2, pen, &stable);
+        contact_tail(B1, B2, cp1, n1, d1, p1, 1e-3, n, p2, pen, &stable, det2);
         if (grp == 0) contract(n, nullptr, p2, 7, 4);
         else if (grp == 1) { contract(n, nullptr, p2, 11, 3); for (int i = 0; i < 3; ++i) out[4 + i] = -out[11 + i]; }
         else contract(n, nullptr, p2, 17, 3);
@@ -226,7 +227,7 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
                     tri[v][i] = d;
                 }
             D n[3], p1[3], p2[3], pen;
-            contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable);
+            contact_from_bary(B1, B2, tri, abc, 1e-3, n, p1, p2, pen, &stable, det2);
             for (int s = 0; s < 3; ++s) {
                 double acc = 0.0;
                 for (int i = 0; i < 3; ++i) acc += gbar[i] * n[i].d[s] + gbar[3 + i] * p1[i].d[s] + gbar[6 + i] * p2[i].d[s];
@@ -661,10 +662,12 @@ __global__ void __launch_bounds__(64) bwd_post_kernel(DssWorld W_arg, DssAdjoint
         cross(v2, p2, w2p);
         cross(n, v1, nw1);
         cross(n, v2, nw2);
+        // (stop_contact_grad: h = Jc v is formed from a detached Jc -- no gradient to the geometry, the one to v stays)
+        const double jg = (W.grad_flags & DSS_GRAD_STOP_CONTACT) ? 0.0 : jvbar;
         for (int i = 0; i < 3; ++i) {
-            nbar[i] += jvbar * (w1p[i] + v1[3 + i] - w2p[i] - v2[3 + i]);
-            p1bar[i] += jvbar * nw1[i];
-            p2bar[i] -= jvbar * nw2[i];
+            nbar[i] += jg * (w1p[i] + v1[3 + i] - w2p[i] - v2[3 + i]);
+            p1bar[i] += jg * nw1[i];
+            p2bar[i] -= jg * nw2[i];
             a_geom[(size_t)i * MX + c] = nbar[i];
         }
         for (int i = 0; i < 3; ++i) { a_geom[(size_t)(3 + i) * MX + c] = p1bar[i]; a_geom[(size_t)(6 + i) * MX + c] = p2bar[i]; }
@@ -754,6 +757,10 @@ void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stre
 #else
 namespace dss {
 void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stream);
+int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
+                              const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
+                              const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream);     // lcp_contact.hip
 }
 
 extern "C" {
@@ -766,9 +773,11 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream_)
     hipStream_t stream = (hipStream_t)stream_;
     if (W->shape_rare) dss::launch_bwd_pre_all(*W, *A, stream);
     else hipLaunchKernelGGL(bwd_pre_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
-    int rc = dss_lcp_contact_backward(W->Mblk, W->Je, W->cop, W->cop_body, A->bw_nc, A->bw_active, W->B, W->nb, W->neq,
-                                      W->maxc, W->fric_dirs, W->x, W->lam, W->slack, W->nu, A->a_x, A->dMblk, A->dpvec,
-                                      A->dcop, nullptr, nullptr, stream_);
+    // rows of G whose dependence on the contact geometry carries gradient: 1 normal (Jc), 2 friction (Jf)
+    const int rows = ((W->grad_flags & DSS_GRAD_STOP_CONTACT) ? 0 : 1) | ((W->grad_flags & DSS_GRAD_STOP_FRICTION) ? 0 : 2);
+    int rc = dss::lcp_contact_backward_rows(W->Mblk, W->Je, W->cop, W->cop_body, A->bw_nc, A->bw_active, W->B, W->nb, W->neq,
+                                            W->maxc, W->fric_dirs, W->x, W->lam, W->slack, W->nu, A->a_x, A->dMblk, A->dpvec,
+                                            A->dcop, nullptr, nullptr, rows, stream_);
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_post_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;

@@ -107,7 +107,7 @@ def mesh_table(meshes, vgrads=None):
 
 class BatchEngine:
     def __init__(self, spec, dt=1.0 / 30, eps=1e-3, tol=1e-8, fric_dirs=8, maxc=64, max_cand=1024, max_pc=32,
-                 max_sub=0, strict_no_pen=True, toc_diff=True, lcp_max_iter=10, backend=None):
+                 max_sub=0, strict_no_pen=True, toc_diff=True, lcp_max_iter=10, backend=None, grad_flags=0):
         """``spec``: numpy arrays pose [B,nb,7], vel [B,nb,6], mass, inertia [B,nb,3,3], restitution, fric,
         fext [B,nb,6], shape_type, shape_prm [B,nb,3], shape_aux [B,nb] (optional), mesh_id [B,nb], meshes [(verts, faces)...],
         no_contact [nb,nb] (optional), Je [B,neq,6nb] (optional)."""
@@ -172,6 +172,7 @@ class BatchEngine:
         W.B, W.nb, W.neq, W.maxc, W.fric_dirs = B, nb, neq, maxc, fric_dirs
         W.max_cand, W.max_pc, W.nmesh = max_cand, max_pc, len(spec["meshes"])
         W.strict_no_pen, W.toc_diff, W.lcp_max_iter = int(strict_no_pen), int(toc_diff), lcp_max_iter
+        W.grad_flags = int(grad_flags)     # 1 stop_contact_grad | 2 stop_friction_grad | 4 detach_contact_b2 (reverse sweep only)
         W.eps, W.tol, W.dt = eps, tol, dt
         # Kernel variant (narrowphase.hip, step_bwd.hip): the lean one knows box / sphere / cylinder and thins contact
         # clusters in LDS; the full one has every primitive and is prepared for level-set meshes (coincident contact

@@ -83,11 +83,15 @@ class BatchWorld3D:
 
     def __init__(self, spec, params=None, dt=Defaults3D.DT, eps=Defaults3D.EPSILON, tol=Defaults3D.TOL,
                  fric_dirs=Defaults3D.FRIC_DIRS, strict_no_penetration=True, time_of_contact_diff=True, device=None,
-                 max_substeps=1024, maxc=96, max_cand=1024, max_pc=32):
+                 max_substeps=1024, maxc=96, max_cand=1024, max_pc=32, stop_contact_grad=False, stop_friction_grad=False,
+                 detach_contact_b2=False):
         dev = torch.device(device) if device is not None else Defaults3D.DEVICE
+        # the reference's gradient switches (physics3d/world.py:33-37): Jc / Jf built from detached contact geometry, the
+        # contact point in body 2's frame a constant -- forward results are the same, the reverse sweep drops those paths
+        flags = (1 if stop_contact_grad else 0) | (2 if stop_friction_grad else 0) | (4 if detach_contact_b2 else 0)
         self.engine = BatchEngine(spec, dt=dt, eps=eps, tol=tol, fric_dirs=fric_dirs, maxc=maxc, max_cand=max_cand,
                                   max_pc=max_pc, max_sub=max_substeps, strict_no_pen=strict_no_penetration,
-                                  toc_diff=time_of_contact_diff, backend=TorchBackend(dev))
+                                  toc_diff=time_of_contact_diff, backend=TorchBackend(dev), grad_flags=flags)
         E = self.engine
         self.device, self.dt = dev, dt
         self.B, self.nb = E.B, E.nb
@@ -160,8 +164,8 @@ class World3D(BatchWorld3D):
                  fric_dirs=Defaults3D.FRIC_DIRS, post_stab=Defaults3D.POST_STABILIZATION, strict_no_penetration=True,
                  time_of_contact_diff=True, stop_contact_grad=False, stop_friction_grad=False, detach_contact_b2=False,
                  device=None, max_substeps=1024):
-        if post_stab or stop_contact_grad or stop_friction_grad or detach_contact_b2:
-            raise NotImplementedError("post_stab / stop_*_grad / detach_contact_b2 are not built on the HIP path yet")
+        if post_stab:
+            raise NotImplementedError("post_stab (engines.py:85-121) is not built on the HIP path")
         from . import engines as engines_module
         self.engine_plugin = engine() if isinstance(engine, type) else getattr(engines_module, engine)()
         self.bodies = bodies
@@ -216,7 +220,8 @@ class World3D(BatchWorld3D):
         dense = any(len(b.faces_np) > 20000 and id(b) not in pinned for b in bodies)
         super().__init__(spec, None, dt, eps, tol, fric_dirs, strict_no_penetration, time_of_contact_diff, device,
                          max_substeps, maxc=4 * maxc if dense else maxc, max_cand=16384 if dense else 1024,
-                         max_pc=128 if dense else 32)
+                         max_pc=128 if dense else 32, stop_contact_grad=stop_contact_grad, stop_friction_grad=stop_friction_grad,
+                         detach_contact_b2=detach_contact_b2)
         self.pose = st(lambda b: b.p).to(self.device)      # keep the graph to leaf poses / velocities
         self.vel = st(lambda b: b.v).to(self.device)
         self.eps, self.tol, self.fric_dirs = eps, tol, fric_dirs

@@ -17,7 +17,7 @@ _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 # (name, kind) kind: 'i' int scalar, 'd' double scalar, 'pd' double*, 'pi' int*, 'pb' uint8*
 FIELDS = [
     ("B", "i"), ("nb", "i"), ("neq", "i"), ("maxc", "i"), ("fric_dirs", "i"), ("max_cand", "i"), ("max_pc", "i"),
-    ("nmesh", "i"), ("strict_no_pen", "i"), ("toc_diff", "i"), ("lcp_max_iter", "i"), ("shape_rare", "i"),
+    ("nmesh", "i"), ("strict_no_pen", "i"), ("toc_diff", "i"), ("lcp_max_iter", "i"), ("shape_rare", "i"), ("grad_flags", "i"),
     ("eps", "d"), ("tol", "d"), ("dt", "d"),
     ("pose", "pd"), ("vel", "pd"),
     ("mass", "pd"), ("inertia", "pd"), ("restitution", "pd"), ("fric", "pd"), ("fext", "pd"),

@@ -126,6 +126,7 @@ typedef struct DssWorld {
     int shape_rare;   /* 0 = lean kernel variants: every shape_type is box / sphere / cylinder and no normal cluster of a
                          body pair exceeds 1024 contacts (analytic meshes); 1 = full variants (all primitives, level-set
                          meshes).  See narrowphase.hip. */
+    int grad_flags;   /* World3D's gradient switches (physics3d/world.py:33-37), reverse sweep only: DSS_GRAD_* */
     double eps, tol, dt;   /* Defaults3D.EPSILON / TOL (utils.py:45-48), world dt */
     /* body state [B][nb][7] / [B][nb][6] */
     double *pose, *vel;
@@ -234,6 +235,9 @@ typedef struct DssWorld {
                                 gradient-list evaluation of every round (bench roofline); NULL in production */
 } DssWorld;
 
+#define DSS_GRAD_STOP_CONTACT 1    /* stop_contact_grad: Jc (and h = Jc v) from detached contact geometry, world.py:59-62 */
+#define DSS_GRAD_STOP_FRICTION 2   /* stop_friction_grad: Jf from detached contact geometry, world.py:77-80 */
+#define DSS_GRAD_DETACH_B2 4       /* detach_contact_b2: the contact point in body 2's frame is a constant, contacts.py:175-178 */
 #define DSS_FACE_NORMAL1 (1 << 30)        /* flag in a contact's face word: normal = -R1 n1 (body 1's), not R2 n2 */
 #define DSS_FACE_ID(w) ((w) & (DSS_FACE_NORMAL1 - 1))
 #define DSS_N_ACTIVE_OVERFLOW (1 << 30)   /* set in n_active[0] once any scene's overflow word is non-zero */

@@ -107,6 +107,8 @@ def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
     d["dt"], d["eps"], d["tol"], d["fric_dirs"], d["toc_diff"] = w.dt, w.eps, w.tol, w.fric_dirs, int(toc)
     d["fixed"] = np.array(fixed, np.int32)
     d["strict_no_pen"] = int(w.strict_no_pen)
+    d["grad_flags"] = (1 if world_kw.get("stop_contact_grad") else 0) | (2 if world_kw.get("stop_friction_grad") else 0) | \
+                      (4 if world_kw.get("detach_contact_b2") else 0)
     b0, g0 = contacts_arrays(w.contacts)
     d["init_body"], d["init_geom"] = b0, g0
     d["init_stable"], d["init_lap"] = contact_record.lookup(w.contacts, MAXC)
@@ -176,6 +178,10 @@ CASES = {
     "rollout_levelset_sphere": (lambda: scenes.levelset_sphere(), dict(nsteps=12, store_mesh=False)),
     "rollout_levelset_cylinder": (lambda: scenes.levelset_cylinder(), dict(nsteps=8, store_mesh=False)),
     "rollout_levelset_box": (lambda: scenes.levelset_box(), dict(nsteps=3, store_mesh=False)),
+    # World3D's gradient switches (physics3d/world.py:33-37) on the tilted box drop: same trajectory, other gradients
+    "rollout_boxdrop_stop_contact": (lambda: scenes.box_drop(seed=7), dict(nsteps=12, stop_contact_grad=True)),
+    "rollout_boxdrop_stop_friction": (lambda: scenes.box_drop(seed=7), dict(nsteps=12, stop_friction_grad=True)),
+    "rollout_boxdrop_detach_b2": (lambda: scenes.box_drop(seed=7), dict(nsteps=12, detach_contact_b2=True)),
     # level-set rounded box at rest on a rounded-rimmed side: a true 3-D hull of thousands of nearly coplanar points
     "rollout_rounded_rest": (lambda: scenes.rounded_rest(), dict(nsteps=4, store_mesh=False)),
     "rollout_brick": (lambda: scenes.rounded_drop("brick"), dict(nsteps=10, store_mesh=False)),

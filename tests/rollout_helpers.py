@@ -41,6 +41,8 @@ def engine_kwargs(g, **over):
               toc_diff=bool(g["toc_diff"]), maxc=64, max_cand=1024, max_pc=32)
     if "strict_no_pen" in g:
         kw["strict_no_pen"] = bool(g["strict_no_pen"])
+    if "grad_flags" in g:
+        kw["grad_flags"] = int(g["grad_flags"])
     kw.update(over)
     return kw
 

@@ -223,3 +223,37 @@ def test_config3_scene_at_full_batch_replicas_are_bit_identical_and_match_the_re
     assert np.isfinite(gp).all() and (gp == gp[:1]).all() and (gm == gm[:1]).all()
     for s in (0, 511, 1023):
         R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]), tol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["rollout_boxdrop_stop_contact", "rollout_boxdrop_stop_friction", "rollout_boxdrop_detach_b2"])
+def test_gradient_switches_of_world3d_match_reference(name):
+    """World3D(stop_contact_grad / stop_friction_grad / detach_contact_b2) (sdf_physics/physics3d/world.py:33-37, 59-62, 77-80;
+    contacts.py:175-178): the tilted box drop -- same trajectory as without the switch, and d sum|pos_T|^2 / d dims equal to
+    the reference's autograd value with that switch (which differs from the plain one in every component) to 1e-5."""
+    g, E = make(name, 2, max_sub=96)
+    assert int(E.W.grad_flags) == int(g["grad_flags"]) != 0
+    R.rollout_and_sweep(E, 12)
+    k = len(g["traj_t"]) - 1
+    assert (E.get("nsub") == len(g["traj_t"])).all()
+    assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8
+    plain = R.load_rollout("rollout_boxdrop")
+    assert np.abs(plain["traj_p"][k] - g["traj_p"][k]).max() == 0.0          # the switches act on the reverse sweep only
+    assert np.abs(plain["grad_0"] - g["grad_0"]).max() > 1e-2
+    R.check_gradients(E, g, tol=1e-5)
+
+
+def test_world3d_accepts_the_gradient_switches():
+    from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, TotalConstraint3D, World3D
+    import torch
+    floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True)
+    dims = torch.tensor([0.5, 0.4, 0.3], dtype=torch.float64, requires_grad=True)
+    b = SDFBox([0.0, 0.3, 0.0], dims, vel=[0.3, 0.1, 0, 0.2, 0, 0], custom_mesh=True, custom_inertia=True)
+    b.add_force(Gravity3D())
+    w = World3D([floor, b], [TotalConstraint3D(floor)], stop_contact_grad=True, stop_friction_grad=True, detach_contact_b2=True)
+    assert int(w.engine.W.grad_flags) == 7
+    for _ in range(6):
+        w.step(fixed_dt=True)
+    (b.p[4:] ** 2).sum().backward()
+    assert torch.isfinite(dims.grad).all()
+    with pytest.raises(NotImplementedError):
+        World3D([floor, b], [TotalConstraint3D(floor)], post_stab=True)
