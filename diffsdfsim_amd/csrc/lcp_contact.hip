@@ -1204,8 +1204,10 @@ __global__ void __launch_bounds__(64)
 lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double *cop_, const int *cbody_,
                             const int *ncs, const int *active, int nb, int neq, int maxc, const double *x_, const double *lam_,
                             const double *slack_, const double *nu_, const double *dl_dx_, double *dMblk_,
-                            double *dpvec_, double *dcop_, double *dA_, double *db_, int rows)
+                            double *dpvec_, double *dcop_, double *dA_, double *db_, int rows, const int *slot, int Btot)
 {
+    // slot != NULL: lam_ / slack_ are the bases of the stepper's tape ([max_sub][B][NR][maxc]) and scene sc reads the record of
+    // sub-step slot[sc] in place (the reverse sweep used to copy 40 KB per scene into [B][NR][maxc] arrays first)
     // rows: which rows of G pass gradient to the contact geometry they are built from -- 1 the normal row (Jc), 2 the
     // friction rows (Jf); World3D's stop_contact_grad / stop_friction_grad build the others from detached geometry
     constexpr int NR = Geo<ND>::NR, NF = Geo<ND>::NF;
@@ -1221,7 +1223,8 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
     L.Ag = A;
     const double *cop = cop_ + (size_t)sc * NF * maxc;
     const int *cbody = cbody_ + (size_t)sc * 2 * maxc;
-    const double *lam = lam_ + (size_t)sc * NR * maxc, *slack = slack_ + (size_t)sc * NR * maxc;
+    const size_t rec = slot ? (size_t)slot[sc] * Btot + sc : (size_t)sc;
+    const double *lam = lam_ + rec * NR * maxc, *slack = slack_ + rec * NR * maxc;
     double *dcop = dcop_ + (size_t)sc * NF * maxc;
     int nc = ncs[sc];
     if (nc > maxc) nc = maxc;
@@ -1321,7 +1324,7 @@ namespace dss {
 int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
                               const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
                               const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
-                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream);
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, const int *slot, void *stream);
 }
 namespace {
 inline bool dims_ok(int B, int nb, int neq, int maxc, int fd)
@@ -1386,7 +1389,7 @@ int dss_lcp_contact_backward(const double *Mblk, const double *A, const double *
                              double *dpvec, double *dcop, double *dA, double *db, void *stream)
 {
     return dss::lcp_contact_backward_rows(Mblk, A, cop, cbody, nc, active, B, nb, neq, maxc, fric_dirs, x, lam, slack, nu, dl_dx, dMblk,
-                                          dpvec, dcop, dA, db, 3, stream);
+                                          dpvec, dcop, dA, db, 3, nullptr, stream);
 }
 
 }  // extern "C"
@@ -1395,7 +1398,7 @@ namespace dss {
 int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
                               const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
                               const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
-                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream)
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, const int *slot, void *stream)
 {
     if (!dims_ok(B, nb, neq, maxc, fric_dirs)) return DSS_E_BADARG;
     if (!Mblk || !cop || !cbody || !nc || !x || !lam || !slack || !dl_dx || !dMblk || !dpvec || !dcop) return DSS_E_BADARG;
@@ -1405,10 +1408,10 @@ int lcp_contact_backward_rows(const double *Mblk, const double *A, const double 
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     if (fric_dirs == 8)
         hipLaunchKernelGGL(lcp_contact_backward_kernel<4>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows, slot, B);
     else
         hipLaunchKernelGGL(lcp_contact_backward_kernel<2>, dim3(B), dim3(64), lds, (hipStream_t)stream, Mblk, A, cop, cbody,
-                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows);
+                           nc, active, nb, neq, maxc, x, lam, slack, nu, dl_dx, dMblk, dpvec, dcop, dA, db, rows, slot, B);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
 }
 }  // namespace dss

@@ -24,6 +24,9 @@
 
 #include "../../include/diffsdfsim_hip.h"
 #include "contact_geom.h"
+#if !DSS_ALL_SHAPES
+#include "contact_rev.h"
+#endif
 #include "wave_utils.h"
 
 namespace {
@@ -100,6 +103,9 @@ template <class T> __device__ inline void attach_grid(const DssWorld &W, int sc,
 #endif
 // lin1 / lin2: igr_lin records of a neural body 1 / body 2 for this contact (NULL: analytic body); stable_in >= 0: which
 // body's normal the contact used, decided by the caller (for neural bodies the Laplacian probes are not repeated).
+// Forward mode (five dual-number passes): the full variant (every primitive, neural / grid bodies, mesh-vertex adjoints).  The
+// lean variant -- box / sphere / cylinder, what the benchmark configs run -- uses the reverse-mode adjoint of contact_rev.h.
+#if DSS_ALL_SHAPES || defined(DSS_BWD_FORWARD_MODE)
 __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int b1, int b2, int face,
                             const double *abc, const double *gbar, double *out, double *g_verts,
                             const double *lin1 = nullptr, const double *lin2 = nullptr, int stable_in = -1)
@@ -237,6 +243,8 @@ __device__ void contact_vjp(const DssWorld &W, int sc, const double *pose_n, int
     }
 #endif
 }
+
+#endif   // forward-mode contact_vjp
 
 #if DSS_ALL_SHAPES
 // ---- neural SDF bodies in the reverse sweep ------------------------------------------------------------------------------
@@ -467,7 +475,11 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
     }
 
     // (a) contacts detected after the sub-step: geometry adjoint -> pose after the sub-step, shape params
+#if defined(DSS_BWD_SKIP_A)
+    for (int c = lane; c < 0; c += 64) {
+#else
     for (int c = lane; c < v.nc_n; c += 64) {
+#endif
         double gb[9], out[20];
         for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
         const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
@@ -490,7 +502,22 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
 #endif
         // the forward pass's normal choice travels with the face id: the Laplacian probes are not repeated
         if (st < 0) st = (v.face_n[c] & DSS_FACE_NORMAL1) ? 0 : 1;
+#if DSS_ALL_SHAPES || defined(DSS_BWD_FORWARD_MODE)
         contact_vjp(W, sc, v.pose_n, v.body_n[c], v.body_n[MX + c], DSS_FACE_ID(v.face_n[c]), abc, gb, out, A.g_verts, l1, l2, st);
+#else
+        {   // reverse mode (contact_rev.h): one value pass, one adjoint pass
+            const int b1 = v.body_n[c], b2 = v.body_n[MX + c];
+            const size_t i1 = (size_t)sc * nb + b1, i2 = (size_t)sc * nb + b2;
+            const int mesh = W.mesh_id[i1];
+            const int voff = W.mesh_voff[mesh];
+            const int *fv = W.faces + (size_t)(W.mesh_foff[mesh] + DSS_FACE_ID(v.face_n[c])) * 3;
+            double tv[3][3], tg[3][3];
+            for (int vv = 0; vv < 3; ++vv)
+                for (int i = 0; i < 3; ++i) { tv[vv][i] = W.verts[(size_t)(voff + fv[vv]) * 3 + i]; tg[vv][i] = W.vgrad[(size_t)(voff + fv[vv]) * 3 + i]; }
+            contact_vjp_rev(v.pose_n + 7 * b1, v.pose_n + 7 * b2, W.shape_type[i1], W.shape_type[i2], W.shape_prm + i1 * 3, W.shape_prm + i2 * 3,
+                            tv, tg, abc, gb, st, (W.grad_flags & DSS_GRAD_DETACH_B2) != 0, out);
+        }
+#endif
         for (int i = 0; i < 20; ++i) cs[(size_t)i * MX + c] = out[i];
     }
     __syncthreads();
@@ -534,7 +561,11 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
         if (lane == 0) A.cur_slot[sc] = -2;
         return;
     }
+#if defined(DSS_BWD_SKIP_B)
+    if (lane < 0) {
+#else
     if (lane < nb) {
+#endif
         double ap[7];
         for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i] ;
         // (b) pose_n = integrate(pose_k, v_new, dt): adjoint -> pose_k, v_new
@@ -604,10 +635,6 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
         for (int i = 0; i < 3; ++i) { cop[(size_t)(o + i) * MX + c] = p1[i]; cop[(size_t)(o + 3 + i) * MX + c] = p2[i]; }
         cop[(size_t)(o + 6) * MX + c] = 0.5 * (W.fric[(size_t)sc * nb + b1] + W.fric[(size_t)sc * nb + b2]);
         cop[(size_t)(o + 7) * MX + c] = 0.0;  // h does not enter the backward system (lcp.py:176-183)
-        for (int q = 0; q < NR; ++q) {
-            W.lam[((size_t)sc * NR + q) * MX + c] = v.lam[(size_t)q * MX + c];
-            W.slack[((size_t)sc * NR + q) * MX + c] = v.slack[(size_t)q * MX + c];
-        }
     }
     if (lane == 0) A.bw_nc[sc] = v.nc_k;
 }
@@ -760,7 +787,7 @@ void launch_bwd_pre_all(const DssWorld &W, const DssAdjoint &A, hipStream_t stre
 int lcp_contact_backward_rows(const double *Mblk, const double *A, const double *cop, const int *cbody, const int *nc,
                               const int *active, int B, int nb, int neq, int maxc, int fric_dirs, const double *x,
                               const double *lam, const double *slack, const double *nu, const double *dl_dx, double *dMblk,
-                              double *dpvec, double *dcop, double *dA, double *db, int rows, void *stream);     // lcp_contact.hip
+                              double *dpvec, double *dcop, double *dA, double *db, int rows, const int *slot, void *stream);     // lcp_contact.hip
 }
 
 extern "C" {
@@ -776,8 +803,8 @@ int dss_step_backward(const DssWorld *W, const DssAdjoint *A, void *stream_)
     // rows of G whose dependence on the contact geometry carries gradient: 1 normal (Jc), 2 friction (Jf)
     const int rows = ((W->grad_flags & DSS_GRAD_STOP_CONTACT) ? 0 : 1) | ((W->grad_flags & DSS_GRAD_STOP_FRICTION) ? 0 : 2);
     int rc = dss::lcp_contact_backward_rows(W->Mblk, W->Je, W->cop, W->cop_body, A->bw_nc, A->bw_active, W->B, W->nb, W->neq,
-                                            W->maxc, W->fric_dirs, W->x, W->lam, W->slack, W->nu, A->a_x, A->dMblk, A->dpvec,
-                                            A->dcop, nullptr, nullptr, rows, stream_);
+                                            W->maxc, W->fric_dirs, W->x, W->tp_lam, W->tp_slack, W->nu, A->a_x, A->dMblk, A->dpvec,
+                                            A->dcop, nullptr, nullptr, rows, A->cur_slot, stream_);      // (multipliers read from the tape in place)
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_post_kernel, dim3(W->B), dim3(64), 0, stream, *W, *A);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
