@@ -380,17 +380,39 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
     const int flags = init ? 0 : W.tp_flags[(size_t)k * W.B + sc];
     const int ev = flags & 1;
     double dt_int = 0.0;   // d(loss)/d(dt) through the pose integration, seed = pose adjoint before the TOC terms
+    // Jacobian of this body's move (Body3D.move, bodies.py:488-496: q' = quat(exp(w dt)) (x) q, x' = x + v dt) from ONE
+    // dual-number pass over theta = w dt: d q'/d theta (4 x 3).  Everything else follows in closed form -- d/dw = dt d/dtheta,
+    // d/d dt = sum_i w_i d/dtheta_i, q' is linear in q (adjoint = conj(dq) (x) .), x' is affine -- where four full passes
+    // (one seed, seven, six and one) used to set this kernel's register footprint.
+    double Jt[4][3], dqv[4] = {1.0, 0.0, 0.0, 0.0}, qsg = 1.0, vnw[6] = {0, 0, 0, 0, 0, 0};
+    for (int o = 0; o < 4; ++o) for (int s3 = 0; s3 < 3; ++s3) Jt[o][s3] = 0.0;
+    if (!init && lane < nb) {
+        typedef Dual<3> D;
+        for (int i = 0; i < 6; ++i) vnw[i] = -v.x[6 * lane + i];
+        D w[3], R[9], dq[4], qk[4], o4[4];
+        for (int i = 0; i < 3; ++i) { w[i] = D(vnw[i] * v.dt); w[i].d[i] = 1.0; }
+        so3_exp(w, R);
+        mat_to_quat(R, dq);
+        for (int i = 0; i < 4; ++i) qk[i] = D(v.pose_k[7 * lane + i]);
+        quat_raw_mul(dq, qk, o4);
+        qsg = o4[0].v < 0.0 ? -1.0 : 1.0;      // quaternion_multiply standardises to a non-negative real part
+        for (int o = 0; o < 4; ++o) { dqv[o] = dq[o].v; for (int s3 = 0; s3 < 3; ++s3) Jt[o][s3] = qsg * o4[o].d[s3]; }
+    }
+    // adjoint of the move for a pose adjoint ap[7]: -> pose_k (apk), v_new (avn), dt (returned)
+    auto move_adjoint = [&](const double *ap, double *apk, double *avn) -> double {
+        double th[3], adt = 0.0;
+        for (int s3 = 0; s3 < 3; ++s3) th[s3] = ap[0] * Jt[0][s3] + ap[1] * Jt[1][s3] + ap[2] * Jt[2][s3] + ap[3] * Jt[3][s3];
+        for (int i = 0; i < 3; ++i) { adt += th[i] * vnw[i] + ap[4 + i] * vnw[3 + i]; if (avn) { avn[i] = th[i] * v.dt; avn[3 + i] = ap[4 + i] * v.dt; } }
+        if (apk) {
+            const double dc[4] = {dqv[0], -dqv[1], -dqv[2], -dqv[3]}, aq[4] = {qsg * ap[0], qsg * ap[1], qsg * ap[2], qsg * ap[3]};
+            quat_raw_mul(dc, aq, apk);          // <a, dq (x) q> = <conj(dq) (x) a, q>
+            for (int i = 0; i < 3; ++i) apk[4 + i] = ap[4 + i];
+        }
+        return adt;
+    };
     if (!init) {
         double part = 0.0;
-        if (lane < nb) {
-            typedef Dual<1> D;
-            D ps[7], vv[6], out[7], dt(v.dt);
-            dt.d[0] = 1.0;
-            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
-            for (int i = 0; i < 6; ++i) vv[i] = D(-v.x[6 * lane + i]);
-            integrate_pose(ps, vv, dt, out);
-            for (int o = 0; o < 7; ++o) part += a_pose[7 * lane + o] * out[o].d[0];
-        }
+        if (lane < nb) part = move_adjoint(a_pose + 7 * lane, nullptr, nullptr);
         dt_int = wave_sum(part);
     }
     double hc_bar = 0.0;
@@ -446,16 +468,14 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
             const double wgt = -(gq / den) * dtbar_h;
             double in[43], outg[44];
             fill(c, in);
-            for (int grp = 0; grp < 11; ++grp) {
-                typedef Dual<4> D;
+            // one seed per pass: a time-of-contact event is rare (a handful of contacts per rollout), its 43 inputs with four
+            // tangents each were what set this kernel's register and scratch footprint for every launch
+#pragma unroll 1
+            for (int sd = 0; sd < 43; ++sd) {
+                typedef Dual<1> D;
                 D di[43];
-                for (int i = 0; i < 43; ++i) {
-                    di[i] = D(in[i]);
-#pragma unroll
-                    for (int sl = 0; sl < 4; ++sl) if (sl == i - 4 * grp) di[i].d[sl] = 1.0;
-                }
-                const D r = toc_D(di);
-                for (int sl = 0; sl < 4; ++sl) outg[4 * grp + sl] = wgt * r.d[sl];
+                for (int i = 0; i < 43; ++i) { di[i] = D(in[i]); di[i].d[0] = (i == sd) ? 1.0 : 0.0; }
+                outg[sd] = wgt * toc_D(di).d[0];
             }
             // geometry of the new contact
             for (int i = 0; i < 3; ++i) {
@@ -568,36 +588,10 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
 #endif
         double ap[7];
         for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i] ;
-        // (b) pose_n = integrate(pose_k, v_new, dt): adjoint -> pose_k, v_new
-        double vnew[6], apk[7], avn[6];
-        for (int i = 0; i < 6; ++i) vnew[i] = -v.x[6 * lane + i];
-        {
-            typedef Dual<7> D;
-            D ps[7], vv[6], out[7], dt(v.dt);
-            for (int i = 0; i < 7; ++i) { ps[i] = D(v.pose_k[7 * lane + i]); ps[i].d[i] = 1.0; }
-            for (int i = 0; i < 6; ++i) vv[i] = D(vnew[i]);
-            integrate_pose(ps, vv, dt, out);
-            for (int s = 0; s < 7; ++s) { double acc = 0.0; for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[s]; apk[s] = acc; }
-        }
-        {
-            typedef Dual<6> D;
-            D ps[7], vv[6], out[7], dt(v.dt);
-            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
-            for (int i = 0; i < 6; ++i) { vv[i] = D(vnew[i]); vv[i].d[i] = 1.0; }
-            integrate_pose(ps, vv, dt, out);
-            for (int s = 0; s < 6; ++s) { double acc = 0.0; for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[s]; avn[s] = acc; }
-        }
-        {   // d/d(dt) of the integration with the complete pose adjoint (first move and redone move share it)
-            typedef Dual<1> D;
-            D ps[7], vv[6], out[7], dt(v.dt);
-            dt.d[0] = 1.0;
-            for (int i = 0; i < 7; ++i) ps[i] = D(v.pose_k[7 * lane + i]);
-            for (int i = 0; i < 6; ++i) vv[i] = D(vnew[i]);
-            integrate_pose(ps, vv, dt, out);
-            double acc = 0.0;
-            for (int o = 0; o < 7; ++o) acc += ap[o] * out[o].d[0];
-            cs[(size_t)53 * MX + lane] = acc;
-        }
+        // (b) pose_n = integrate(pose_k, v_new, dt): adjoint -> pose_k, v_new, dt (with the complete pose adjoint: first move
+        //     and redone move share it)
+        double apk[7], avn[6];
+        cs[(size_t)53 * MX + lane] = move_adjoint(ap, apk, avn);
         for (int i = 0; i < 7; ++i) a_pose[7 * lane + i] = apk[i];
         // total adjoint of v_new = (later uses, already in a_vel) + (integration); x = -v_new
         for (int i = 0; i < 6; ++i) A.a_x[(size_t)sc * 6 * nb + 6 * lane + i] = -(a_vel[6 * lane + i] + avn[i]);
