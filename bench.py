@@ -361,9 +361,9 @@ def main():
             r.update(achieved=None, frac=None, flops_per_launch=None, flops_note=pmc_note or "no fp64 instruction counters in the PMC file")
         else:
             r.update(achieved=fl / t / 1e12, frac=fl / t / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=fl)
-            vb = pmc_sum(pmc, "valu_busy_frac", *frags)
+            vb = pmc_sum(pmc, "valu_util_per_simd", frags[0])     # of the group's main kernel
             if vb is not None:
-                r["valu_busy_frac"] = vb
+                r["valu_util_per_simd"] = vb     # cycles in which a SIMD issues a VALU instruction / kernel cycles, chip average
         return r
 
     r_lcp = roof_valu("lcp_contact_forward_reg_kernel", lcp_ms, lcp_algorithmic_bytes(E.nb, E.neq, E.fd, nc),
@@ -371,7 +371,7 @@ def main():
                       "serial chain, not by HBM (operands are 35 KB per scene)", ("lcp_contact_forward",))
     r_det = roof_valu("narrowphase_kernel (+overlap_kernel, compact_contacts_kernel)", det_ms, detect_algorithmic_bytes(E),
                       "Frank-Wolfe / SDF evaluation: fp64 VALU bound (IEEE div/sqrt sequences), not HBM",
-                      ("narrowphase_kernel", "overlap_kernel", "compact_contacts"))
+                      ("narrowphase_kernel<false>", "overlap_kernel", "compact_contacts"))
     extra = {}
     if neural and igr_ms:
         ms = np.array(igr_ms)

@@ -42,7 +42,11 @@ for k, e in kern.items():
     # SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD summed over the chip; SQ_BUSY_CYCLES per shader engine: report the plain
     # ratio the round-1 profiles used (VALU-issue cycles / wave-resident cycles) as an indication, not an absolute
     if "SQ_ACTIVE_INST_VALU_avg" in e and e.get("SQ_WAVE_CYCLES_avg"):
-        e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU_avg"] / e["SQ_WAVE_CYCLES_avg"]
+        e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU_avg"] / e["SQ_WAVE_CYCLES_avg"]       # per resident wave
+    if "SQ_ACTIVE_INST_VALU_avg" in e and e.get("GRBM_GUI_ACTIVE_avg"):
+        # per SIMD: quad-cycles of VALU issue summed over all waves x 4 / (kernel cycles x 1024 SIMDs); GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs
+        e["valu_util_per_simd"] = e["SQ_ACTIVE_INST_VALU_avg"] * 4.0 / (e["GRBM_GUI_ACTIVE_avg"] / 8.0 * 1024.0)
     if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in e and e.get("GRBM_GUI_ACTIVE_avg"):
         # busy cycles are summed over the 1024 SIMDs of the chip (MI355X guide): fraction of the kernel's cycles the matrix
         # pipes were busy, averaged over SIMDs
