@@ -325,10 +325,9 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
         };
         // batches of BATCH contacts regardless of where the (body1, body2) runs end; the run sum is flushed into K
         // whenever the pair changes (uniform branch), so the accumulation order stays the contact order
-#ifndef DSS_ASM_BATCH
-#define DSS_ASM_BATCH 2
-#endif
-        constexpr int BATCH = DSS_ASM_BATCH;
+        // (two contacts' operands in flight: deeper look-ahead costs more in registers than the LDS latency it hides --
+        // eight deep was 5 % slower for the whole kernel)
+        constexpr int BATCH = 2;
         int pb1 = -1, pb2 = -1;
         double acc[3] = {0.0, 0.0, 0.0};
         auto flush = [&]() {
@@ -344,12 +343,8 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             for (int u = 0; u < BATCH; ++u) rd(c + u, t[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-#if defined(DSS_ASM_NOBRANCH)
-                if (pb1 < 0) { pb1 = cbody[0]; pb2 = cbody[L.maxc]; }
-#else
                 const int b1 = cbody[c + u], b2 = cbody[L.maxc + c + u];
                 if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
-#endif
                 double o[3];
                 term(t[u], o);
 #pragma unroll

@@ -495,11 +495,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
     }
 
     // (a) contacts detected after the sub-step: geometry adjoint -> pose after the sub-step, shape params
-#if defined(DSS_BWD_SKIP_A)
-    for (int c = lane; c < 0; c += 64) {
-#else
     for (int c = lane; c < v.nc_n; c += 64) {
-#endif
         double gb[9], out[20];
         for (int i = 0; i < 9; ++i) gb[i] = a_geom[(size_t)i * MX + c];
         const double abc[3] = {v.abc_n[c], v.abc_n[MX + c], v.abc_n[2 * MX + c]};
@@ -581,11 +577,7 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
         if (lane == 0) A.cur_slot[sc] = -2;
         return;
     }
-#if defined(DSS_BWD_SKIP_B)
-    if (lane < 0) {
-#else
     if (lane < nb) {
-#endif
         double ap[7];
         for (int i = 0; i < 7; ++i) ap[i] = a_pose[7 * lane + i] ;
         // (b) pose_n = integrate(pose_k, v_new, dt): adjoint -> pose_k, v_new, dt (with the complete pose adjoint: first move

