@@ -177,11 +177,14 @@ struct Lds {
     int *bl_start;  // [nb+1]
     int *bl_ent;    // [2*maxc]  contact*2 + side
     int *cb;        // [2][maxc] body ids (LDS copy)
+    int *run_end;   // [RUNCAP] end (exclusive) of every run of consecutive contacts of one (body1, body2); nruns = 0: not tabulated
+    int nruns;
     int n, kn, lda, nz, neq, nb, maxc;
     double *kf;     // global: [n][64] factored rows parked between the solves of an iteration (register path)
     const double *Ag;   // global equality rows [neq][nz]
 };
 
+constexpr int RUNCAP = 64;   // runs of contacts per scene the K assembly walks by table (more: contact by contact)
 // sizes with a register-resident factor/solve: only H = Q + sum P C P^T is assembled in LDS, the equality rows join
 // in registers and the factored rows are parked in the (L2-resident) workspace between the two solves of an iteration
 __host__ __device__ inline bool reg_path(int n) { return n == 54 || n == 18; }
@@ -193,7 +196,7 @@ __host__ __device__ inline size_t lds_doubles(int nb, int neq, int maxc)
 __host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
 {
     const int n = 6 * nb + neq;
-    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 4 * maxc + 4) * 4;
+    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 4 * maxc + 4 + RUNCAP) * 4;
 }
 __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc)
 {
@@ -215,7 +218,9 @@ __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc
     L.piv = ip; ip += L.n;
     L.bl_start = ip; ip += nb + 1;
     L.bl_ent = ip; ip += 2 * maxc;
-    L.cb = ip;
+    L.cb = ip; ip += 2 * maxc;
+    L.run_end = ip;
+    L.nruns = 0;
 }
 
 // per-body contact lists in ascending contact order (deterministic gathers)
@@ -242,6 +247,18 @@ __device__ void build_lists(Lds &L, const int *cbody_g, int nc)
             if (cbody[L.maxc + c] == lane) L.bl_ent[o++] = 2 * c + 1;
         }
     }
+    // runs of consecutive contacts of the same (body1, body2) -- detection emits contacts pair by pair -- for assemble_K:
+    // contact c ends a run if its successor has other bodies; ordered compaction of the ends by ballot prefix sums
+    int nr = 0;
+    for (int base = 0; base < nc; base += WAVE) {
+        const int c = base + lane;
+        const int endr = c < nc && (c + 1 == nc || cbody[c + 1] != cbody[c] || cbody[L.maxc + c + 1] != cbody[L.maxc + c]);
+        const unsigned long long m = __ballot(endr);
+        const int slot = nr + __popcll(m & ((1ull << lane) - 1ull));
+        if (endr && slot < RUNCAP) L.run_end[slot] = c + 1;
+        nr += __popcll(m);
+    }
+    L.nruns = nr <= RUNCAP ? nr : 0;
     __syncthreads();
 }
 
@@ -337,6 +354,38 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             for (int j = 0; j < 3; ++j) { L.K[row * lda + col + j] += sgn * acc[j]; acc[j] = 0.0; }
         };
         int c = 0;
+        if (L.nruns > 0) {
+            // run by run: bodies and bounds are read once per run (wave-uniform, moved to scalar registers), the loop over
+            // the run's contacts has no data-dependent branch, so the reads of the next contact are in flight while this
+            // one's three entries are formed.  Same order of additions as the contact-by-contact walk below.
+            for (int r = 0; r < L.nruns; ++r) {
+                const int c1 = dss_uniform(L.run_end[r]);
+                pb1 = dss_uniform(cbody[c]); pb2 = dss_uniform(cbody[L.maxc + c]);
+                Rd t0, t1;
+                rd(c, t0);
+                for (; c + 1 < c1; c += 2) {
+                    rd(c + 1, t1);
+                    double o[3];
+                    term(t0, o);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
+                    if (c + 2 < c1) rd(c + 2, t0);
+                    term(t1, o);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
+                }
+                if (c < c1) {
+                    double o[3];
+                    term(t0, o);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
+                    ++c;
+                }
+                flush();
+            }
+            c = nc;
+            pb1 = -1;
+        }
         for (; c + BATCH <= nc; c += BATCH) {
             Rd t[BATCH];
 #pragma unroll
