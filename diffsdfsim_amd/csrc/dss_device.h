@@ -8,6 +8,7 @@
 // lanes of one emulated wavefront meet at every switch point
 inline void dss_wave_sync() { dss_emu::yield(); }
 inline int dss_uniform(int x) { return x; }
+inline int dss_opaque(int x) { return x; }
 inline double dss_uniform(double x) { return x; }
 #else
 #include <hip/hip_runtime.h>
@@ -20,6 +21,8 @@ __device__ __forceinline__ void dss_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// the value, hidden from the optimiser (stops loop-invariant code motion of everything computed from it)
+__device__ __forceinline__ int dss_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // a value every lane of the wavefront agrees on, moved to scalar registers
 __device__ __forceinline__ int dss_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ double dss_uniform(double x)

@@ -207,10 +207,8 @@ void launch(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t 
 {
     constexpr int PTS = (MODE == MODE_VALUE ? 16 : 4) * NG;
     const size_t lds = (size_t)16 * NG * LDX * sizeof(double);
-#if !defined(DSS_EMU)
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)igr_query_kernel<NW, NG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#endif
     long tiles = ((long)n_cap + PTS - 1) / PTS;
     if (Q.n_dev) {
         // The length is only known on the device.  The grid is persistent over the tiles, so ANY size is correct; what it
@@ -242,10 +240,8 @@ template <int PTS> inline long tiles_for(int n_cap, int est)
 template <int NW, int NG> void launch2(const Query &Qv, const Query &Qg, const DssIgrNet &N, int n_cap, int estv, int estg, hipStream_t stream)
 {
     const size_t lds = (size_t)16 * NG * LDX * sizeof(double);
-#if !defined(DSS_EMU)
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)igr_query2_kernel<NW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#endif
     const long tv = tiles_for<16 * NG>(n_cap, estv), tg = tiles_for<4 * NG>(n_cap, estg);
     hipLaunchKernelGGL((igr_query2_kernel<NW, NG>), dim3((unsigned)(tv + tg)), dim3(64 * NW), lds, stream, Qv, Qg, (int)tv, N.W0, N.b0,
                        N.Wp, N.bh, N.W8, N.b8);

@@ -46,13 +46,7 @@ using namespace dss;
 
 // The contact index of a pass, hidden from loop-invariant code motion: otherwise every per-contact address of
 // every pass (hundreds of 64-bit values) is hoisted out of the IPM iteration loop and spilled to scratch memory.
-__device__ __forceinline__ int opaque_lane(int lane)
-{
-#if !defined(DSS_EMU)
-    asm volatile("" : "+v"(lane));
-#endif
-    return lane;
-}
+__device__ __forceinline__ int opaque_lane(int lane) { return dss_opaque(lane); }
 
 template <int ND> struct Geo {
     static constexpr int NR = 2 * ND + 2;       // rows per contact: normal, ND +dirs, ND -dirs, cone

@@ -37,6 +37,8 @@ typedef void *hipStream_t;
 typedef int hipError_t;
 constexpr int hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }   // (LDS is host memory here)
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 typedef void *hipEvent_t;
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
