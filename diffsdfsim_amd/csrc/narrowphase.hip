@@ -458,6 +458,9 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (nmov > G::HCAP) { if (G::BT == 64) return 1; over |= 2; nmov = G::HCAP; }
         G::sync();
     }
+#if defined(DSS_NP_STAT_NMOV)
+    if (tid == 0) W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = nmov;      // (experiment: movers instead of candidates)
+#endif
     if (G::BT == 64 && nmov > 0 && nmov <= 16) {
         // Few movers, one wavefront: the loop is a serial chain (evaluate -> pick a vertex -> move -> evaluate ...)
         // on a handful of lanes.  The step size of iteration k is known in advance (2 / (k + 2), float32), so the
