@@ -30,6 +30,10 @@
 
 #include "np_common.h"
 
+#ifndef DSS_NP_WAVES
+#define DSS_NP_WAVES 3   // waves per SIMD the register allocator must leave room for (= workgroups per CU)
+#endif
+
 namespace {
 // ---- _overlap ---------------------------------------------------------------------------------
 // "Does any vertex of one body lie in the other's query cube", both ways, for every undirected pair.  One workgroup
@@ -45,7 +49,13 @@ __global__ void __launch_bounds__(OV_NT) overlap_kernel(DssWorld W)
     const int nb = W.nb, nup = nb * (nb - 1) / 2, np = npairs_of(nb);
     const int sc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!W.active[sc]) return;
-    if (tid < nb) s_big[tid] = W.mesh_nf[W.mesh_id[(size_t)sc * nb + tid]] > WAVE_ITEM_MAX_FACES;
+    // (a batch with fewer items than the grid has workgroups -- the time of the launch is then the latency of its longest item:
+    // the items that search a big mesh get a whole workgroup, whose four wavefronts scan it a quarter each)
+    const bool few = (long)W.B * np <= 256L * DSS_NP_WAVES;
+    if (tid < nb) {
+        const int nf = W.mesh_nf[W.mesh_id[(size_t)sc * nb + tid]];
+        s_big[tid] = nf > WAVE_ITEM_MAX_FACES || (few && nf > 2048);
+    }
 #if DSS_ALL_SHAPES
     // a pair with a neural SDF body goes to the round-based narrow phase (narrowphase_igr.hip), both directions
     __shared__ unsigned char s_igr[64];
@@ -624,9 +634,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 // cursor, wave cursor, deferred-list length, deferred cursor}; pair_list = three segments of B*npairs.  Every workgroup first helps with the block list (all four
 // wavefronts on one item), then its wavefronts split up and walk the wave list independently.  A wave item that
 // outgrows the wave-sized scratch is appended to the deferred list, which a second launch works off block-wise.
-#ifndef DSS_NP_WAVES
-#define DSS_NP_WAVES 3   // waves per SIMD the register allocator must leave room for (= workgroups per CU)
-#endif
 union NpScratch {
 #if !defined(DSS_NP_EXP_STOP)
     ScratchT<BlockGroup> blk;

@@ -63,7 +63,8 @@ def test_gradients_match_reference_autograd(name, nsteps, copies):
 def test_pair_that_outgrows_the_wavefront_scratch_matches_reference():
     """A wide flat box on the floor has ~800 contacts before thinning: the wavefront that starts the pair hands it
     to the deferred list, a whole workgroup redoes it.  Same contacts, same trajectory as the reference."""
-    g, E = make("rollout_bigbox", 2, max_sub=16, max_cand=2048, maxc=64)
+    # (400 replicas: with fewer work items than the grid has workgroups such an item is given a whole workgroup from the start)
+    g, E = make("rollout_bigbox", 400, max_sub=16, max_cand=2048, maxc=64)
     for _ in range(3):
         E.step()
     assert int(E.get("n_pairs")[4]) >= 1, "the pair was expected to be deferred"
@@ -71,8 +72,13 @@ def test_pair_that_outgrows_the_wavefront_scratch_matches_reference():
     k = len(g["traj_t"]) - 1
     assert (E.get("nsub") == len(g["traj_t"])).all()
     assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-8 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
-    for s in (0, 1):
+    for s in (0, 399):
         R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]))
+    # ... and the same pair started on a workgroup (a batch of two)
+    g2, E2 = make("rollout_bigbox", 2, max_sub=16, max_cand=2048, maxc=64)
+    for _ in range(3):
+        E2.step()
+    assert int(E2.get("n_pairs")[4]) == 0 and np.array_equal(E2.get("pose")[0], E.get("pose")[0])
 
 
 def test_config3_scene_seven_box_stack_matches_reference():
