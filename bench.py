@@ -88,6 +88,16 @@ def pmc_sum(pmc, key, *frags):
     return tot if hit else None
 
 
+def pmc_ratio(pmc, num, den, den_scale, *frags):
+    """sum(num) / (den_scale * sum(den)) over all dispatches of the kernels that match (per-kernel averages x dispatch counts)."""
+    a = b = 0.0
+    for k, v in pmc.items():
+        if any(f in k for f in frags) and num in v and den in v:
+            n = v.get("dispatches", 1)
+            a += v[num] * n; b += v[den] * n
+    return a / (den_scale * b) if b > 0 else None
+
+
 def cpu_baseline_lcp(E, n_sample, threads):
     """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of batch.py / lcp.py) on the
     operands the GPU just solved, for a bounded sample of scenes; once on one thread, once with OpenMP over scenes."""
@@ -391,7 +401,7 @@ def main():
                                              "avg_points_gradient_list": float(np.mean([g_ for (a, g_), b in zip(igr_pts, big) if b]))},
                  "points_evaluated": {"value_only": nv, "with_gradient": ng, "per_step": (nv + ng) / K,
                                       "value_list_by_round": [int(x) for x in tot[2::2][:12]], "gradient_list_by_round": [int(x) for x in tot[3::2][:12]]},
-                 "mfma_busy_frac": pmc_sum(pmc, "mfma_busy_frac", "igr_query2_kernel"),
+                 "mfma_busy_frac": pmc_ratio(pmc, "SQ_VALU_MFMA_BUSY_CYCLES_avg", "GRBM_GUI_ACTIVE_avg", 1024.0 / 8.0, "igr_query2_kernel"),
                  "sampled_attempts": {"detection_ms_mean": float(np.mean([det_ms[a] for a, _ in igr_attempts])),
                                       "network_ms_mean": float(ms.sum() / max(1, len(igr_attempts))),
                                       "detection_ms_all_attempts_mean": float(det_ms.mean())},

@@ -1,6 +1,7 @@
 #!/bin/bash
+# Dev aid (GPU box): the tuning summary of the bench for the product library and every exp_libs/lib_*.so
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 200 python3 "$1" 2>&1 | grep -v Warn | tail -3 || exit 1
+echo "== product"; bash tools/bench_brief.sh "$@" || exit 1
 for f in exp_libs/lib_*.so; do
-  DSS_LIB_PATH=$PWD/$f timeout -k 10 200 python3 "$1" 2>&1 | grep -v Warn | tail -3 || exit 1
+  echo "== $f"; DSS_LIB_PATH=$PWD/$f bash tools/bench_brief.sh "$@" || exit 1
 done

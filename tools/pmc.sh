@@ -50,7 +50,8 @@ for k, e in kern.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in e and e.get("GRBM_GUI_ACTIVE_avg"):
         # busy cycles are summed over the 1024 SIMDs of the chip (MI355X guide): fraction of the kernel's cycles the matrix
         # pipes were busy, averaged over SIMDs
-        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (e["GRBM_GUI_ACTIVE_avg"] * 1024.0)
+        # (GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = that / 8)
+        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (e["GRBM_GUI_ACTIVE_avg"] / 8.0 * 1024.0)
 lib = "diffsdfsim_amd/csrc/libdiffsdfsim_hip.so"
 res = {"config": int(cfg), "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16], "kernels": kern}
 json.dump(res, open("gpurun_out/r2_pmc_config%s.json" % cfg, "w"), indent=1)
