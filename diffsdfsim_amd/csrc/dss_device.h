@@ -9,6 +9,7 @@
 inline void dss_wave_sync() { dss_emu::yield(); }
 inline int dss_uniform(int x) { return x; }
 inline int dss_opaque(int x) { return x; }
+inline double dss_rcp(double x) { return 1.0 / x; }
 inline double dss_uniform(double x) { return x; }
 #else
 #include <hip/hip_runtime.h>
@@ -23,6 +24,13 @@ __device__ __forceinline__ void dss_wave_sync()
 }
 // the value, hidden from the optimiser (stops loop-invariant code motion of everything computed from it)
 __device__ __forceinline__ int dss_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+// 1 / x to within an ulp or two: v_rcp_f64 and two Newton steps (for arguments well inside the normal range)
+__device__ __forceinline__ double dss_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
 // a value every lane of the wavefront agrees on, moved to scalar registers
 __device__ __forceinline__ int dss_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ double dss_uniform(double x)

@@ -37,14 +37,59 @@ enum { MODE_XYZ = DSS_IGR_XYZ, MODE_LATENT = DSS_IGR_LATENT, MODE_VALUE = DSS_IG
 __device__ inline acc4 mfma(double a, double b, acc4 c) { return mfma_f64_16x16x4(a, b, c); }
 __device__ inline double &comp(acc4 &v, int i) { return acc_comp(v, i); }
 
-// softplus(z, beta=100, threshold=20) and its derivative, torch.nn.Softplus semantics
+// softplus(z, beta=100, threshold=20) and its derivative, torch.nn.Softplus semantics:
+//   h = z (100 z > 20), else log1p(exp(100 z)) / 100;   dh = sigmoid(100 z).
+// Evaluated as max(z, 0) + log1p(u) / 100 with u = exp(-|100 z|) in (0, 1], by hand: the network spends 1024 of these per
+// point on the vector ALU next to the matrix work, and the library's exp + log1p + quotient are general-purpose (every range,
+// every special case) where this needs one argument range each.
+//   exp(-a):   a = k ln2 + r, |r| <= ln2 / 2, Taylor to r^12 (remainder 2e-16), ldexp
+//   log1p(u):  w = 1 + u, f = w or w / 2 in (1/sqrt 2, sqrt 2], s = (f - 1) / (f + 1), log f = 2 s (1 + s^2/3 + ... + s^20/21)
+//              (|s| <= 0.1716: remainder 2e-17), plus (u - (w - 1)) / w for the bits of u the sum 1 + u rounded away
+// Absolute error of h below 3e-18 + 2 ulp over the whole range (tests/emu/check_softplus.cpp against long double).
 __device__ inline void softplus100(double z, double &h, double &dh)
 {
-    const double bz = 100.0 * z;
-    const bool lin = bz > 20.0;
-    const double e = exp(lin ? 20.0 : bz);   // branch-free: both sides evaluated on a clamped argument
-    h = lin ? z : log1p(e) / 100.0;
-    dh = lin ? 1.0 : e / (1.0 + e);
+    const double y = 100.0 * z;
+    const bool lin = y > 20.0;
+    const double a = fabs(lin ? 20.0 : y);
+    // u = exp(-a)
+    const double kf = __builtin_rint(-a * 1.4426950408889634074);
+    double r = __builtin_fma(-kf, 6.93147180369123816490e-01, -a);
+    r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double u = ldexp(p, (int)kf);
+    // log1p(u)
+    const double w = 1.0 + u, lo = u - (w - 1.0);
+    const bool big = w > 1.4142135623730951;
+    const double f = big ? 0.5 * w : w;
+    const double s = (f - 1.0) * dss_rcp(f + 1.0), s2 = s * s;
+    double q = 2.0 / 21.0;
+    q = __builtin_fma(q, s2, 2.0 / 19.0);
+    q = __builtin_fma(q, s2, 2.0 / 17.0);
+    q = __builtin_fma(q, s2, 2.0 / 15.0);
+    q = __builtin_fma(q, s2, 2.0 / 13.0);
+    q = __builtin_fma(q, s2, 2.0 / 11.0);
+    q = __builtin_fma(q, s2, 2.0 / 9.0);
+    q = __builtin_fma(q, s2, 2.0 / 7.0);
+    q = __builtin_fma(q, s2, 2.0 / 5.0);
+    q = __builtin_fma(q, s2, 2.0 / 3.0);
+    q = __builtin_fma(q, s2, 2.0);
+    const double rw = dss_rcp(w);
+    double l1p = __builtin_fma(q, s, big ? 6.93147180559945286227e-01 : 0.0);
+    l1p = __builtin_fma(lo, rw, l1p);
+    h = lin ? z : (y > 0.0 ? z : 0.0) + l1p * 0.01;
+    dh = lin ? 1.0 : (y >= 0.0 ? rw : u * rw);
 }
 
 struct Query {
