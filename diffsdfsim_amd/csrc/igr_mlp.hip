@@ -294,16 +294,13 @@ template <int NW, int NG> void launch2(const Query &Qv, const Query &Qg, const D
 
 template <int MODE> void launch_mode(const Query &Q, const DssIgrNet &N, int n_cap, int est, hipStream_t stream)
 {
-    // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 4 row groups, which quarters
-    // the L2 weight traffic per point; small ones (a Frank-Wolfe round moves a few points per item): one row group per
+    // big batches (grid builds, the candidate rounds of a large scene batch): 4 waves share 2 row groups (32 KB of LDS: four
+    // workgroups per CU, so that one's softplus epilogue hides under another's MFMAs; measured 41.9 / 58.1 TFLOP/s without /
+    // with tangents against 39.7 / 57.8 for 4 row groups); small ones (a Frank-Wolfe round moves a few points per item): one row group per
     // workgroup, a quarter of the latency of a pass and four times as many workgroups to spread over the chip.
     // All variants give bit-identical results (a point's row never mixes with its tile-mates').
     const int n = Q.n_dev ? (est < 0 ? n_cap : est) : n_cap;
-#if defined(DSS_IGR_BIG_NW)      // (experiment builds: another variant for the big lists)
-    if (n >= 16 * 1024) launch<DSS_IGR_BIG_NW, DSS_IGR_BIG_NG, MODE>(Q, N, n_cap, est, stream);
-#else
-    if (n >= 16 * 1024) launch<4, 4, MODE>(Q, N, n_cap, est, stream);
-#endif
+    if (n >= 16 * 1024) launch<4, 2, MODE>(Q, N, n_cap, est, stream);
     else if (n >= 2 * 1024) launch<2, 2, MODE>(Q, N, n_cap, est, stream);
     else launch<4, 1, MODE>(Q, N, n_cap, est, stream);
 }
@@ -331,7 +328,7 @@ int launch_igr_pair(const DssIgrNet &N, const double *pts_v, const int *lat_v, c
     Query Qv{pts_v, lat_v, latents, lat_stride, n_v, n_cap, sdf_v, nullptr}, Qg{pts_g, lat_g, latents, lat_stride, n_g, n_cap, sdf_g, grad_g};
     // variant by the work expected (a gradient point is four rows): see launch_mode
     const long rows = (est_v < 0 || est_g < 0) ? (long)n_cap : (long)est_v + 4L * est_g;
-    if (rows >= 16 * 1024) launch2<4, 4>(Qv, Qg, N, n_cap, est_v, est_g, stream);
+    if (rows >= 16 * 1024) launch2<4, 2>(Qv, Qg, N, n_cap, est_v, est_g, stream);
     else if (rows >= 2 * 1024) launch2<2, 2>(Qv, Qg, N, n_cap, est_v, est_g, stream);
     else launch2<4, 1>(Qv, Qg, N, n_cap, est_v, est_g, stream);
     return hipGetLastError() == hipSuccess ? DSS_OK : DSS_E_UNSUPPORTED;
