@@ -208,11 +208,46 @@ __device__ void advance(const DssWorld &W, ScratchT<G> &S, int it, int round, in
             // b neural: every face whose centroid lies in b's query cube needs phi_b there before it can be judged.  Such
             // "tentative" faces can be many (all of a floor's faces under the body), so they live in the query list itself
             // (point + face id as the tag), not in the item's candidate scratch; two passes: count, then reserve and write.
+            // b analytic: the runs of 256 faces that can hold a candidate are listed first, one culling box per thread.  Beyond
+            // the query-cube test a run is dropped if b's surface is out of reach of every face in it: b's SDF is an exact
+            // distance (box / sphere / cylinder / ...: 1-Lipschitz), the run's box holds every face's bounding sphere, so
+            // phi_b(centroid) >= phi_b(box centre) - |half diagonal| and rad <= the smallest half extent; a face with
+            // phi_b >= rad + eps is no candidate (contacts.py:52).  A neural body's whole mesh lies in the query cube of a floor
+            // it is nowhere near -- 60 k faces read and tested per item and attempt, for nothing, without this.
+            const int nch = (A.nf + RUN - 1) / RUN;
+            int nrun = -1;
+            if (!Bigr && nch <= G::HCAP) {
+                nrun = 0;
+                for (int cb0 = 0; cb0 < nch; cb0 += G::BT) {
+                    const int ch = cb0 + tid;
+                    int keep = 0;
+                    if (ch < nch) {
+                        const double *bx = fbox + (size_t)ch * 6;
+                        keep = box_hits(reg, bx);
+                        if (keep && Bd.g.shape.type != SHAPE_GRID && Bd.g.shape.type != SHAPE_BOWL) {
+                            double m[3], e2 = 0.0, emin = INFINITY;
+                            for (int i = 0; i < 3; ++i) {
+                                m[i] = 0.5 * (bx[i] + bx[3 + i]);
+                                const double e = 0.5 * (bx[3 + i] - bx[i]);
+                                e2 += e * e; emin = fmin(emin, e);
+                            }
+                            double pu[3], u, gdum[3];
+                            for (int i = 0; i < 3; ++i) pu[i] = (R12[3 * i] * m[0] + R12[3 * i + 1] * m[1] + R12[3 * i + 2] * m[2] + t12[i]) / sB;
+                            sdf_unit(Bd.g.shape, pu, u, gdum, false);
+                            if (u * sB - sqrt(e2) >= emin + W.eps + 1e-9 * (1.0 + sB)) keep = 0;
+                        }
+                    }
+                    const int slot = compact_slot(keep, nrun, S);
+                    if (slot >= 0) S.hidx[slot] = ch;
+                }
+                G::sync();
+            }
             int ntent = 0;
             for (int pass = 0; pass < (Bigr ? 2 : 1); ++pass) {
                 int cnt = 0;
-                for (int base = 0; base < A.nf; base += G::BT) {
-                    if (!box_hits(reg, fbox + (size_t)(base / RUN) * 6)) continue;     // (uniform over the group)
+                for (int it = 0; it < (nrun >= 0 ? nrun : nch); ++it) {
+                    const int base = (nrun >= 0 ? S.hidx[it] : it) * RUN;
+                    if (nrun < 0 && !box_hits(reg, fbox + (size_t)(base / RUN) * 6)) continue;     // (uniform over the group)
                     const int f = base + tid;
                     int flag = 0;
                     double pqr[3][3], x[3] = {0, 0, 0}, rad = 0.0;
@@ -271,9 +306,15 @@ __device__ void advance(const DssWorld &W, ScratchT<G> &S, int it, int round, in
                     store_c(c, k);
                     cstate[k] = 0;
                 }
+                // Iteration 0 looks at every candidate; a candidate whose |improvement| <= tol is frozen for good (gamma = 0: x no
+                // longer changes, every later evaluation repeats this one), so afterwards only the movers -- typically a handful
+                // on the rim of a contact patch, out of hundreds of candidates -- are walked, through a packed list.
+                int nlist = ncand;          // entries of the list the iterations walk: all candidates, then the movers
+                bool packed = false;
                 for (int itn = 0; itn < 32; ++itn) {
                     int moving = 0, anyp = 0;
-                    for (int k = tid; k < ncand; k += G::BT) {
+                    for (int j = tid; j < nlist; j += G::BT) {
+                        const int k = packed ? S.hidx[j] : j;
                         if (cstate[k] != 0) continue;
                         Cand c; load_c(c, k);
                         double phi, g[3];
@@ -285,11 +326,23 @@ __device__ void advance(const DssWorld &W, ScratchT<G> &S, int it, int round, in
                     }
                     const int mv = G::any(moving), pn = G::any(anyp);
                     if (!mv || pn) break;           // all gamma == 0, or a penetrating point (contacts.py:74-77)
-                    for (int k = tid; k < ncand; k += G::BT) {
+                    for (int j = tid; j < nlist; j += G::BT) {
+                        const int k = packed ? S.hidx[j] : j;
                         if (cstate[k] != 0) continue;
                         const float gm = (float)CB(25, k);
                         if (gm == 0.0f) { cstate[k] = -1; continue; }      // froze: x no longer changes
                         Cand c; load_c(c, k); fw_apply(c, gm, (int)CB(26, k)); store_c(c, k);
+                    }
+                    if (itn == 0) {
+                        G::sync();
+                        int nm = 0;
+                        for (int base = 0; base < ncand; base += G::BT) {
+                            const int k = base + tid;
+                            const int slot = compact_slot(k < ncand && cstate[k] == 0, nm, S);
+                            if (slot >= 0 && slot < G::HCAP) S.hidx[slot] = k;
+                        }
+                        G::sync();
+                        if (nm <= G::HCAP) { nlist = nm; packed = true; }      // (more movers than the list holds: keep walking them all)
                     }
                 }
                 G::sync();
