@@ -255,10 +255,29 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     if (G::BT == 64) {
         // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
         // flight, survivors packed in ascending order into LDS; (b) the full test on dense lanes.
+        // A run is also dropped if b's surface is out of reach of every face in it: b's SDF is an exact distance (1-Lipschitz),
+        // the run's box holds every face's bounding sphere, so phi_b(centroid) >= phi_b(box centre) - |half diagonal| and
+        // rad <= the smallest half extent, and a face with phi_b >= rad + eps is no candidate (contacts.py:52).  A level-set
+        // body's whole mesh lies in the query cube of a floor it is nowhere near.
+        auto run_far = [&](const double *bx) -> bool {
+#if DSS_ALL_SHAPES
+            if (Bd.g.shape.type == SHAPE_GRID || Bd.g.shape.type == SHAPE_BOWL || Bd.g.shape.type == SHAPE_IGR) return false;
+#endif
+            double m[3], e2 = 0.0, emin = INFINITY;
+            for (int i = 0; i < 3; ++i) {
+                m[i] = 0.5 * (bx[i] + bx[3 + i]);
+                const double e = 0.5 * (bx[3 + i] - bx[i]);
+                e2 += e * e; emin = fmin(emin, e);
+            }
+            double pu[3], u, gdum[3];
+            for (int i = 0; i < 3; ++i) pu[i] = (R12[3 * i] * m[0] + R12[3 * i + 1] * m[1] + R12[3 * i + 2] * m[2] + t12[i]) / sB;
+            sdf_unit(Bd.g.shape, pu, u, gdum, false);
+            return u * sB - sqrt(e2) >= emin + W.eps + 1e-9 * (1.0 + sB);
+        };
         int npass = 0;
         for (int base = 0; base < nch; base += G::BT) {
             const int ch = base + tid;
-            const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6);
+            const int hit = ch < nch && box_hits(reg, fbox + (size_t)ch * 6) && !run_far(fbox + (size_t)ch * 6);
             const int slot = compact_slot(hit, npass, S);
             if (slot >= 0 && slot < G::HCAP) S.hidx[slot] = ch;
         }
