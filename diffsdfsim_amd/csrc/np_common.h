@@ -249,11 +249,12 @@ struct HullGlobal {
 // unique extreme start point in any of the probe directions, or more faces than the edge list holds.
 template <class P_> struct WrapEdge {
     double a[3], e[3], le2;
-    int ia, ib;     // ia < 0: `a` is a virtual point (the start)
+    double nx[3];   // e x (x - a), x = the third vertex of the face this edge was found in (hasx), which lies behind the new face
+    int ia, ib, ix; // ia < 0: `a` is a virtual point (the start); ix < 0: no neighbouring face yet
 };
 template <class P_> __device__ inline bool wrap_valid(const P_ &P, const WrapEdge<P_> &E, int c, double tolf)
 {
-    if (c == E.ia || c == E.ib) return false;
+    if (c == E.ia || c == E.ib || c == E.ix) return false;
     const double u[3] = {P.hp(c, 0) - E.a[0], P.hp(c, 1) - E.a[1], P.hp(c, 2) - E.a[2]};
     double m[3];
     cross(E.e, u, m);
@@ -272,7 +273,17 @@ template <class P_> __device__ inline bool wrap_better(const P_ &P, const WrapEd
     const double s = (m1[0] * u2[0] + m1[1] * u2[1] + m1[2] * u2[2]) / lm;      // c2 above (+) / below the plane (a, b, c1)
     if (s > tolf) return true;
     if (s < -tolf) return false;
-    // in the plane: seen from outside the facet's polygon runs counter-clockwise, a -> b -> c with every point left of b -> c
+    // In the plane.  An edge that is a DIAGONAL of a coplanar facet (the fan over a facet's polygon produces them) has
+    // coplanar points on both sides of its line: those on the side of the face it was found in are behind it.
+    if (E.ix >= 0) {
+        double m2[3];
+        cross(E.e, u2, m2);
+        if (m1[0] * m2[0] + m1[1] * m2[1] + m1[2] * m2[2] < 0.0) {       // c1 and c2 on opposite sides of the edge's line
+            const double b1 = m1[0] * E.nx[0] + m1[1] * E.nx[1] + m1[2] * E.nx[2];
+            return b1 > 0.0;      // c1 lies on x's side: c2 takes its place
+        }
+    }
+    // seen from outside the facet's polygon runs counter-clockwise, a -> b -> c with every point left of b -> c
     const double v1[3] = {u1[0] - E.e[0], u1[1] - E.e[1], u1[2] - E.e[2]}, v2[3] = {u2[0] - E.e[0], u2[1] - E.e[1], u2[2] - E.e[2]};
     double x[3];
     cross(v1, v2, x);
@@ -301,10 +312,10 @@ template <class G, class P_> __device__ int wrap_next(ScratchT<G> &S, const P_ &
 }
 template <class G, class P_> __device__ bool hull3_wrap(ScratchT<G> &S, const P_ &P, int m, double amax, double tolf, double dtol2)
 {
-    constexpr int EMAX = (G::CHCAP * 4) / 3;       // directed edges the list holds (three int arrays in S.woff)
+    constexpr int EMAX = (G::CHCAP * 4) / 4;       // directed edges the list holds (four int arrays in S.woff)
     if (EMAX < 96) return false;
     const int tid = G::tid();
-    int *eu = S.woff, *ev = S.woff + EMAX, *est = S.woff + 2 * EMAX;     // est: 0 = needs its face, 1 = has it
+    int *eu = S.woff, *ev = S.woff + EMAX, *est = S.woff + 2 * EMAX, *ex = S.woff + 3 * EMAX;   // est: 0 = needs its face, 1 = has it; ex: third vertex of the face found
     // a start vertex: the extreme point of a direction in which it is the only one (no facet or edge perpendicular to it)
     const double probes[3][3] = {{0.5411961001, 0.6363961031, 0.4209517757}, {-0.3826834324, 0.5879378012, 0.7126966451},
                                  {0.7071067812, -0.4539904997, 0.5420261274}};
@@ -336,48 +347,104 @@ template <class G, class P_> __device__ bool hull3_wrap(ScratchT<G> &S, const P_
         cross(gdir, ex, d);
         const double ld = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), L = 1.0 + amax;
         for (int k = 0; k < 3; ++k) { E.e[k] = d[k] / ld * L; E.a[k] = P.hp(i0, k) - E.e[k]; }
-        E.le2 = L * L; E.ia = -1; E.ib = i0;
+        E.le2 = L * L; E.ia = -1; E.ib = i0; E.ix = -1;
+        E.nx[0] = E.nx[1] = E.nx[2] = 0.0;
     }
     const int i1 = wrap_next(S, P, E, m, tolf, dtol2);
     if (i1 < 0) return false;
-    if (tid == 0) { eu[0] = i0; ev[0] = i1; est[0] = 0; eu[1] = i1; ev[1] = i0; est[1] = 0; P.setf(i0, 1); P.setf(i1, 1); S.wave_tot[0] = 2; }
+    if (tid == 0) { eu[0] = i0; ev[0] = i1; est[0] = 0; ex[0] = -1; eu[1] = i1; ev[1] = i0; est[1] = 0; ex[1] = -1; P.setf(i0, 1); P.setf(i1, 1); S.wave_tot[0] = 2; }
     G::sync();
     int ne = 2;
-    for (int q = 0; q < ne; ++q) {
-        if (est[q]) continue;           // (uniform: LDS word read by every thread)
-        const int u = eu[q], v = ev[q];
-        for (int k = 0; k < 3; ++k) { E.a[k] = P.hp(u, k); E.e[k] = P.hp(v, k) - E.a[k]; }
-        E.le2 = E.e[0] * E.e[0] + E.e[1] * E.e[1] + E.e[2] * E.e[2]; E.ia = u; E.ib = v;
-        const int w = wrap_next(S, P, E, m, tolf, dtol2);
-        if (w < 0) return false;
-        // the face (u, v, w): its directed edges have their face now, their reverses need one unless they have it already
-        if (tid < 4) S.red_i[tid] = -1;
+    // directed edge a -> b of the current facet gets its face; its reverse needs one unless it is listed already
+    auto settle = [&](int a, int b, int third) {
+        if (tid < 2) S.red_i[tid] = -1;
         G::sync();
         for (int e = tid; e < ne; e += G::BT) {
-            const int a = eu[e], b = ev[e];
-            if (a == v && b == w) S.red_i[0] = e;
-            if (a == w && b == u) S.red_i[1] = e;
-            if (a == w && b == v) S.red_i[2] = e;
-            if (a == u && b == w) S.red_i[3] = e;
+            if (eu[e] == a && ev[e] == b) S.red_i[0] = e;
+            if (eu[e] == b && ev[e] == a) S.red_i[1] = e;
         }
         G::sync();
         if (tid == 0) {
             int n2 = ne;
-            est[q] = 1;
-            auto put = [&](int slot, int a, int b, int state) {
-                const int e = S.red_i[slot];
-                if (e >= 0) { if (state) est[e] = 1; return; }
-                if (n2 < EMAX) { eu[n2] = a; ev[n2] = b; est[n2] = state; }
-                ++n2;
-            };
-            put(0, v, w, 1); put(1, w, u, 1); put(2, w, v, 0); put(3, u, w, 0);
-            P.setf(w, 1);
+            if (S.red_i[0] >= 0) est[S.red_i[0]] = 1;
+            else { if (n2 < EMAX) { eu[n2] = a; ev[n2] = b; est[n2] = 1; ex[n2] = -1; } ++n2; }
+            if (S.red_i[1] < 0) { if (n2 < EMAX) { eu[n2] = b; ev[n2] = a; est[n2] = 0; ex[n2] = third; } ++n2; }
             S.wave_tot[0] = n2;
         }
         G::sync();
         ne = S.wave_tot[0];
         G::sync();
-        if (ne > EMAX) return false;
+    };
+    for (int q = 0; q < ne; ++q) {
+        if (est[q]) continue;           // (uniform: LDS word read by every thread)
+        const int u = eu[q], v = ev[q];
+        for (int k = 0; k < 3; ++k) { E.a[k] = P.hp(u, k); E.e[k] = P.hp(v, k) - E.a[k]; }
+        E.le2 = E.e[0] * E.e[0] + E.e[1] * E.e[1] + E.e[2] * E.e[2]; E.ia = u; E.ib = v; E.ix = ex[q];
+        if (E.ix >= 0) {
+            const double xr[3] = {P.hp(E.ix, 0) - E.a[0], P.hp(E.ix, 1) - E.a[1], P.hp(E.ix, 2) - E.a[2]};
+            cross(E.e, xr, E.nx);
+        }
+        const int w = wrap_next(S, P, E, m, tolf, dtol2);
+        if (w < 0) return false;
+        // The facet through (u, v, w) as a WHOLE polygon: from v -> w on, the next vertex is the next of the 2-D wrap among the
+        // points in the facet's plane, until the walk is back at u.  Every boundary edge gets its face at once and no
+        // diagonal is ever created: a fan over the polygon would depend on the edge the facet is entered through, and two
+        // entries (its neighbours are found in any order) would triangulate it in two incompatible ways.
+        double nrm[3];
+        {
+            const double uw[3] = {P.hp(w, 0) - E.a[0], P.hp(w, 1) - E.a[1], P.hp(w, 2) - E.a[2]};
+            cross(E.e, uw, nrm);
+            const double ln = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+            for (int k = 0; k < 3; ++k) nrm[k] /= ln;
+        }
+        const double org[3] = {E.a[0], E.a[1], E.a[2]};
+        settle(u, v, w);
+        int pa = v, pb = w;       // the edge being added; then the walk goes on from pb
+        for (int step = 0; step < m; ++step) {
+            if (tid == 0) P.setf(pb, 1);
+            settle(pa, pb, u == pa ? w : u);      // (third vertex for the reverse edge: any vertex of this facet off the edge)
+            if (ne > EMAX) return false;
+            if (pb == u) break;
+            // next vertex after pb: among the points in the plane, the one with every other to the left of pb -> c
+            const double bx = P.hp(pb, 0), by = P.hp(pb, 1), bz = P.hp(pb, 2);
+            auto better = [&](int c1, int c2) -> bool {
+                if (c2 < 0) return false;
+                if (c1 < 0) return true;
+                const double v1[3] = {P.hp(c1, 0) - bx, P.hp(c1, 1) - by, P.hp(c1, 2) - bz}, v2[3] = {P.hp(c2, 0) - bx, P.hp(c2, 1) - by, P.hp(c2, 2) - bz};
+                double x[3];
+                cross(v1, v2, x);
+                const double cr = x[0] * nrm[0] + x[1] * nrm[1] + x[2] * nrm[2];
+                const double lb = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], lq = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+                const double c2s = cr * cr, t2 = dtol2 * fmax(lb, lq);
+                if (cr < 0.0 && c2s > t2) return true;
+                if (c2s <= t2) return lq > lb || (lq == lb && c2 < c1);
+                return false;
+            };
+            int best = -1;
+            for (int k = tid; k < m; k += G::BT) {
+                if (k == pb) continue;
+                const double d[3] = {P.hp(k, 0) - org[0], P.hp(k, 1) - org[1], P.hp(k, 2) - org[2]};
+                if (fabs(d[0] * nrm[0] + d[1] * nrm[1] + d[2] * nrm[2]) > tolf) continue;          // not in the facet's plane
+                const double r[3] = {P.hp(k, 0) - bx, P.hp(k, 1) - by, P.hp(k, 2) - bz};
+                if (!(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > tolf * tolf)) continue;             // pb itself or a duplicate of it
+                if (better(best, k)) best = k;
+            }
+            S.red_i[tid] = best;
+            G::sync();
+            for (int s2 = G::BT / 2; s2 > 0; s2 >>= 1) {
+                if (tid < s2) { const int a = S.red_i[tid], b = S.red_i[tid + s2]; if (better(a, b)) S.red_i[tid] = b; }
+                G::sync();
+            }
+            int nx2 = S.red_i[0];
+            G::sync();
+            if (nx2 < 0) return false;
+            {   // coincident with the start (a duplicate of u with another index): the polygon is closed
+                const double d[3] = {P.hp(nx2, 0) - org[0], P.hp(nx2, 1) - org[1], P.hp(nx2, 2) - org[2]};
+                if (!(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > tolf * tolf)) nx2 = u;
+            }
+            pa = pb; pb = nx2;
+            if (step + 1 == m) return false;      // (no closed polygon: not to be trusted)
+        }
     }
     return true;
 }
