@@ -12,7 +12,7 @@ from scipy.spatial import ConvexHull
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_hull(pts):
+def run_hull(pts, wave=False):
     out = os.path.join(HERE, "emu", "_build")
     os.makedirs(out, exist_ok=True)
     exe = os.path.join(out, "check_hull3")
@@ -21,7 +21,7 @@ def run_hull(pts):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-I", os.path.join(HERE, "emu"), "-o", exe, src])
     f = os.path.join(out, "hull_pts.bin")
     np.ascontiguousarray(pts, np.float64).tofile(f)
-    r = subprocess.run([exe, f, str(len(pts))], capture_output=True, text=True, check=True)
+    r = subprocess.run([exe, f, str(len(pts))] + (["wave"] if wave else []), capture_output=True, text=True, check=True)
     return np.array(sorted(int(x) for x in r.stdout.split()), np.int64)
 
 
@@ -103,3 +103,47 @@ def test_gift_wrapped_hull_of_points_in_general_position_with_duplicated_vertice
     pts = _place(pts, r)
     mine, ref = run_hull(pts), qhull_vertices(pts)
     assert len(ref) == 70 and np.array_equal(mine, ref), (len(mine), len(ref))
+
+
+def reference_flat_vertices(pts):
+    """contacts.py:126-152 for a flat cluster: Qhull rejects the 3-D input, the coordinate of least variance is dropped and the
+    2-D hull's vertices are kept (one representative per group of coincident points)."""
+    drop = int(np.argmin(pts.var(axis=0, ddof=1)))
+    p2 = np.delete(pts, drop, axis=1)
+    v = ConvexHull(p2).vertices
+    keep = set()
+    for i in v:
+        keep.add(int(np.nonzero(np.abs(pts - pts[i]).max(axis=1) < 1e-12)[0].min()))
+    return np.array(sorted(keep), np.int64)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_flat_cluster_hull_is_the_references_2d_hull(seed):
+    """The common case (a box face on a box face): a few hundred coplanar contact points, rows of them collinear along the
+    patch's edges up to rotation round-off -- the corners of the patch, nothing on the edges, nothing inside."""
+    r = np.random.default_rng(seed)
+    nx, ny = int(r.integers(8, 20)), int(r.integers(8, 20))
+    gx, gy = np.meshgrid(np.linspace(-0.45, 0.5, nx), np.linspace(-0.3, 0.35, ny), indexing="ij")
+    pts = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    if seed % 2:       # an octagonal patch: the overlap of two rectangles turned against each other
+        c, s_ = np.cos(0.3), np.sin(0.3)
+        rot = pts[:, :2] @ np.array([[c, -s_], [s_, c]])
+        pts = pts[(np.abs(rot[:, 0]) < 0.42) & (np.abs(rot[:, 1]) < 0.3)]
+        pts = np.concatenate([pts, pts[r.integers(0, len(pts), 30)]])      # + duplicates
+    pts = _place(pts, r)
+    mine, ref = run_hull(pts), reference_flat_vertices(pts)
+    assert np.array_equal(mine, ref), (mine, ref)
+    if len(pts) <= 384:      # the wavefront flavour (what config 3's items run) must agree
+        assert np.array_equal(run_hull(pts, wave=True), ref)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_small_3d_cluster_hull_in_both_flavours(seed):
+    """Up to 48 distinct points: the brute-force hull (supporting planes over all triples), workgroup and wavefront flavour."""
+    r = np.random.default_rng(seed)
+    v = r.standard_normal((14, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    inner = 0.5 * (2 * r.random((25, 3)) - 1) / np.sqrt(3)
+    pts = np.concatenate([v, inner, v[:5], 0.5 * (v[0] + v[1])[None]]) * np.array([0.3, 0.2, 0.25])      # duplicates, a mid-edge point
+    pts = _place(pts, r)
+    ref = qhull_vertices(pts)
+    assert np.array_equal(run_hull(pts), ref) and np.array_equal(run_hull(pts, wave=True), ref)
