@@ -564,13 +564,9 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
 #if DSS_ALL_SHAPES
             // the distinct points, listed once (workgroup: in the scan's LDS words, free by now; a wavefront's cluster is
             // small enough to walk with its duplicates)
-            constexpr int UCAP = G::BT == 64 ? 1 : 512;
-            const bool listed = G::BT != 64 && mu <= UCAP;
-            if (listed && tid == 0) { int u = 0; for (int k = 0; k < m; ++k) if (P.getf(k) != 3) S.woff[u++] = k; }
-            G::sync();
-            const bool thin = listed || (G::BT == 64 && mu <= 512);
-            const int nu = listed ? mu : m;
-            if (!thin && G::BT != 64) {      // more distinct points than the segment filter takes: the real hull
+            // the workgroup flavour takes the real hull (gift wrapping); the segment filter below remains for the wavefront
+            // flavour (clusters of up to 384 points) and as the fall-back should the wrap not close
+            if (G::BT != 64) {
                 if (hull3_wrap(S, P, m, amax, tolf, dtol2)) {
                     for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
                     G::sync();
@@ -579,6 +575,12 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
                 for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 1) P.setf(k, 0);
                 G::sync();
             }
+            constexpr int UCAP = G::BT == 64 ? 1 : 512;
+            const bool listed = G::BT != 64 && mu <= UCAP;
+            if (listed && tid == 0) { int u = 0; for (int k = 0; k < m; ++k) if (P.getf(k) != 3) S.woff[u++] = k; }
+            G::sync();
+            const bool thin = listed || (G::BT == 64 && mu <= 512);
+            const int nu = listed ? mu : m;
 #else
             const bool thin = false, listed = false;
             const int nu = m;
