@@ -450,12 +450,14 @@ template <class G, class P_> __device__ bool hull3_wrap(ScratchT<G> &S, const P_
 }
 #endif
 
-template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
+// Returns 1 if a wavefront-sized group has to hand the item to a workgroup (full variant: a cluster of more than 48 distinct
+// non-coplanar points gets the gift-wrapped hull, which keeps its edge list in the workgroup's LDS), else 0.
+template <class G, class P_> __device__ int cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
 {
     const int tid = G::tid();
     for (int k = tid; k < m; k += G::BT) P.setf(k, 0);
     G::sync();
-    if (m == 1) { if (tid == 0) P.setf(0, 1); G::sync(); return; }
+    if (m == 1) { if (tid == 0) P.setf(0, 1); G::sync(); return 0; }
     // per-coordinate mean / unbiased variance (torch.var)
     double mean[3], var[3], amax = 0.0;
     for (int d = 0; d < 3; ++d) {
@@ -525,7 +527,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
 #if DSS_ALL_SHAPES
     // workgroup flavour, more points than the pairwise duplicate search below is meant for: gift wrapping
     if (!flat3 && G::BT != 64 && m > 2048) {
-        if (hull3_wrap(S, P, m, amax, tolf, dtol2)) return;
+        if (hull3_wrap(S, P, m, amax, tolf, dtol2)) return 0;
         for (int k = tid; k < m; k += G::BT) P.setf(k, 0);      // could not be trusted: every point is kept (below)
         G::sync();
     }
@@ -533,7 +535,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
     if (!flat3 && m > 2048) {   // beyond what the pairwise duplicate search below is meant for: keep every point
         for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
         G::sync();
-        return;
+        return 0;
     }
     if (!flat3) {
         // Coincident points (candidates of neighbouring faces that converged to a shared mesh vertex -- the rule on a
@@ -566,11 +568,12 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             // small enough to walk with its duplicates)
             // the workgroup flavour takes the real hull (gift wrapping); the segment filter below remains for the wavefront
             // flavour (clusters of up to 384 points) and as the fall-back should the wrap not close
+            if (G::BT == 64) return 1;      // (uniform: every lane sees the same count)
             if (G::BT != 64) {
                 if (hull3_wrap(S, P, m, amax, tolf, dtol2)) {
                     for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 3) P.setf(k, 0);
                     G::sync();
-                    return;
+                    return 0;
                 }
                 for (int k = tid; k < m; k += G::BT) if (P.getf(k) == 1) P.setf(k, 0);
                 G::sync();
@@ -610,7 +613,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             G::sync();
             for (int k = tid; k < m; k += G::BT) { const int f = P.getf(k); P.setf(k, f == 1 ? 1 : 0); }
             G::sync();
-            return;
+            return 0;
         }
         // supporting-plane test over all triples of distinct points.  A point that lies in the triangle of three others
         // (inside it or on one of its edges) is no hull vertex, whatever planes it helps to support: Qhull reports the
@@ -627,7 +630,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         if (m > HULL3_MAX) {  // beyond the brute-force limit: keep every point (superset of the hull)
             for (int k = tid; k < m; k += G::BT) P.setf(k, 1);
             G::sync();
-            return;
+            return 0;
         }
         // supporting-plane test over all triples
         const int ntri = m * m * m;
@@ -669,7 +672,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         for (int qu = tid; qu < mu; qu += G::BT) if (S.red_d[qu] != 0.0) P.setf(S.red_i[qu], 0);
         G::sync();
 #endif
-        return;
+        return 0;
     }
     // ---- 2-D: drop the coordinate of least variance (first index on ties, torch.argmin) ---------
     int drop = 0;
@@ -757,7 +760,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
             cur = nxt;
         }
         G::sync();
-        return;
+        return 0;
     }
     // ---- 1-D: drop the next least-variance coordinate, keep min (and max if the spread > eps) ---
     const int keep = (var[c1] < var[c0]) ? c0 : c1;  // argmin over the remaining two drops the smaller
@@ -773,6 +776,7 @@ template <class G, class P_> __device__ void cluster_hull(ScratchT<G> &S, P_ P, 
         if (P.hp(gmax, keep) - P.hp(gmin, keep) > eps) P.setf(gmax, 1);
     }
     G::sync();
+    return 0;
 }
 // The escape of world.py:345-347 (strict_no_penetration=False and dt already below dt / 2^10): the step goes through with the
 // contacts as _search_contacts left them when it met a penetration (contacts.py:249-272) -- every contact of this direction,
