@@ -450,7 +450,8 @@ template <class G, class P_> __device__ bool hull3_wrap(ScratchT<G> &S, const P_
 }
 #endif
 
-// Returns 1 if a wavefront-sized group has to hand the item to a workgroup (full variant: a cluster of more than 48 distinct
+// Returns 2 (lean variant) if the cluster has more than 48 distinct non-coplanar points -- every one of them is kept and the
+// caller flags the scene; 1 if a wavefront-sized group has to hand the item to a workgroup (full variant: a cluster of more than 48 distinct
 // non-coplanar points gets the gift-wrapped hull, which keeps its edge list in the workgroup's LDS), else 0.
 template <class G, class P_> __device__ int cluster_hull(ScratchT<G> &S, P_ P, int m, double eps)
 {
@@ -613,7 +614,9 @@ template <class G, class P_> __device__ int cluster_hull(ScratchT<G> &S, P_ P, i
             G::sync();
             for (int k = tid; k < m; k += G::BT) { const int f = P.getf(k); P.setf(k, f == 1 ? 1 : 0); }
             G::sync();
-            return 0;
+            // (the lean variant has no exact hull beyond the brute-force limit: what it keeps is a superset, and the caller
+            // reports that the scene needs the full kernel variants)
+            return DSS_ALL_SHAPES ? 0 : 2;
         }
         // supporting-plane test over all triples of distinct points.  A point that lies in the triangle of three others
         // (inside it or on one of its edges) is no hull vertex, whatever planes it helps to support: Qhull reports the

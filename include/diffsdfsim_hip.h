@@ -189,7 +189,7 @@ typedef struct DssWorld {
     int *n_pairs;            /* [8] (index 6 = length of the neural work list igr_list): workgroup-list length, wavefront-list length (one 8-byte aligned pair), their two
                                 work cursors, deferred-list length and cursor */
     int *invalid;            /* [B] penetration > tol found in this attempt */
-    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc, 16 max_sub (tape slots), 32 igr_qcap / igr_items_cap, 64 igr_rounds */
+    int *overflow;           /* [B] capacity exceeded, bit mask: 1 max_cand, 2 more than 1024 moving Frank-Wolfe candidates (lean variant: or contacts of one normal cluster) in a pair, 4 max_pc, 8 maxc, 16 max_sub (tape slots), 32 igr_qcap / igr_items_cap, 64 igr_rounds, 128 (lean variant) a contact cluster that needs the exact hull of the full variant */
     int *pc_count;           /* [B][npairs] */
     int *pc_stats;           /* [B][npairs][2] work done for the pair: face runs tested, candidate faces (bench accounting) */
     int *pc_face;            /* [B][npairs][max_pc] */
