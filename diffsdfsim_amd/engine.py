@@ -284,7 +284,7 @@ class BatchEngine:
                                          "contacts of one normal cluster -- in a body pair"), (4, "max_pc"), (8, "maxc"), (16, "max_sub (tape slots for the backward pass)"),
                                         (32, "igr_qcap (query list of the neural narrow phase)"), (64, "igr_rounds"),
                                         (128, "a contact cluster of more than 48 distinct non-coplanar points, whose hull only the full kernel variants take "
-                                              "exactly: construct the engine with spec['full_kernels'] = True")) if ov[s] & b]
+                                              "exactly: construct the engine with spec['full_kernels'] = True (World3D(..., full_kernels=True))")) if ov[s] & b]
         raise RuntimeError("contact detection exceeded a capacity in scene %d (%s): raise the limit when constructing "
                            "the engine / world -- contacts were dropped, the step is not valid" % (s, ", ".join(names)))
 

@@ -163,7 +163,7 @@ class World3D(BatchWorld3D):
                  contact_callback=Defaults3D.CONTACT, eps=Defaults3D.EPSILON, tol=Defaults3D.TOL,
                  fric_dirs=Defaults3D.FRIC_DIRS, post_stab=Defaults3D.POST_STABILIZATION, strict_no_penetration=True,
                  time_of_contact_diff=True, stop_contact_grad=False, stop_friction_grad=False, detach_contact_b2=False,
-                 device=None, max_substeps=1024):
+                 device=None, max_substeps=1024, full_kernels=None):
         if post_stab:
             raise NotImplementedError("post_stab (engines.py:85-121) is not built on the HIP path")
         from . import engines as engines_module
@@ -204,6 +204,8 @@ class World3D(BatchWorld3D):
                     shape_aux=np.array([[b.shape_aux() for b in bodies]], np.float64),
                     mesh_id=np.arange(nb, dtype=np.int32)[None], meshes=[(b.verts_np, b.faces_np) for b in bodies],
                     mesh_vgrad=[b.vgrad_np for b in bodies], Je=Je, no_contact=nocon)
+        if full_kernels is not None:       # (None: the engine picks the lean kernel variants when every body allows them)
+            spec["full_kernels"] = bool(full_kernels)
         grids = [b for b in bodies if b.shape_type == abi.SHAPE_GRID]
         if grids:
             spec["grids"] = [b.sdf.detach().cpu().numpy() for b in grids]

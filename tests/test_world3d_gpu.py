@@ -186,3 +186,21 @@ def test_loss_on_an_intermediate_step_with_the_world_stepped_further():
 
     a, b = grad_at(20, 20), grad_at(20, 24)
     assert a != 0.0 and a == b, (a, b)
+
+
+def test_world3d_can_be_put_on_the_full_kernel_variants():
+    """`full_kernels=True` (an extra keyword: the exact hull of big contact clusters, every primitive) gives the same step as
+    the lean variants on a scene both can run."""
+    import torch
+    from diffsdfsim_amd.physics3d import Gravity3D, SDFBox, TotalConstraint3D, World3D
+    out = []
+    for full in (None, True):
+        floor = SDFBox([0, -0.5, 0], [4.0, 1.0, 4.0], custom_mesh=True, custom_inertia=True)
+        b = SDFBox([0.0, 0.2505, 0.0], [0.5, 0.5, 0.4], vel=[0.2, 0.1, 0, 0.3, 0, 0], custom_mesh=True, custom_inertia=True)
+        b.add_force(Gravity3D())
+        w = World3D([floor, b], [TotalConstraint3D(floor)], full_kernels=full)
+        assert int(w.engine.W.shape_rare) == int(bool(full))
+        for _ in range(5):
+            w.step(fixed_dt=True)
+        out.append(b.p.detach().cpu().clone())
+    assert torch.equal(out[0], out[1])
