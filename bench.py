@@ -207,9 +207,12 @@ def main():
         # RCCL ("nccl" on ROCm) over xGMI on a real node; DSS_DIST_BACKEND=gloo rehearses the same code path with
         # several ranks sharing one GPU (collectives then go through host copies)
         backend = os.environ.get("DSS_DIST_BACKEND", "nccl")
+        kw = {}
         if not os.environ.get("DSS_BENCH_DRYRUN") and torch.cuda.device_count() > 0:
             torch.cuda.set_device(local % torch.cuda.device_count())     # RCCL binds its communicator to the current device
-        dist.init_process_group(backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
         if os.environ.get("DSS_BENCH_DRYRUN"):   # launcher + rendezvous check without a GPU (tests/test_bench_launcher.py)
             mine = torch.tensor([rank], dtype=torch.int64)
             got = [torch.empty_like(mine) for _ in range(world)]
