@@ -15,8 +15,14 @@ inertia fitting  (experiments/inertia_fitting/optim_shapespace.py)
                                                   t < 0.3 (:71-92); inertia from the body's level-set mesh, differentiable w.r.t. the latent
     fit_inertia_latent(...)                       the loop of :136-250: loss = |v_T - v_T*|^2 + reg |latent|^2
 
+system identification  (experiments/system_identification/optim_sysid.py)
+    push_world(latents, packed, force, mass, fric, ...)   the floor and a neural-SDF body pushed along it (:104-131), per scene its own
+                                                  push, mass and friction coefficient (torch tensors that may require grad)
+    fit_sysid(goal, ...)                          the loop of :184-300 for goal in ('mass', 'force', 'friction')
+
     python -m diffsdfsim_amd.experiments sphere --scenes 64 --iters 100
     python -m diffsdfsim_amd.experiments inertia --scenes 8 --iters 10
+    python -m diffsdfsim_amd.experiments sysid --goal mass --scenes 8 --iters 20
 """
 import argparse
 import math
@@ -254,6 +260,92 @@ def fit_inertia_latent(target_latents, start_latents, torque_dirs, packed, run_t
     return dict(latent=lat.detach().numpy().copy(), target=np.asarray(target_latents), history=hist)
 
 
+# ---- system identification (experiments/system_identification/optim_sysid.py) --------------------------------------------
+def push_world(latents, packed, force, mass, fric, run_steps, floor_dims=(20.0, 1.0, 20.0), restitution=0.0, g=10.0, res=128, device=None,
+               mesh_cache=None):
+    """optim_sysid.py:104-131 (`make_world`) for one scene per latent code: the floor and a neural-SDF body (scale 1) set down
+    on it (2 eps above, by its mesh's lowest vertex), gravity, a constant push (force[:, 0] along x, force[:, 1] along z),
+    strict_no_penetration=False, fric_dirs=8.  `force` [B,2], `mass` [B], `fric` [B] (both bodies, as in the experiment) are
+    torch tensors and may require grad: the batch's parameters are built from them (inertia = mass x the mesh's unit inertia)."""
+    latents = np.asarray(latents, np.float64)
+    B, nb = latents.shape[0], 2
+    spec, cache = scenes._base(B, nb), {}
+    fd = np.asarray(floor_dims, np.float64)
+    scenes._floor(spec, cache, fd, 0.0, restitution)
+    spec["shape_aux"] = np.zeros((B, nb))
+    spec["igr_net"] = packed
+    spec["shape_type"][:, 1] = abi.SHAPE_IGR
+    spec["shape_aux"][:, 1] = 1.0
+    Iunit = []
+    for s in range(B):
+        key = tuple(latents[s])
+        if mesh_cache is None or key not in mesh_cache:
+            v, f = meshsdf.igr_mesh(torch.tensor(latents[s], dtype=torch.float64), packed, res=res)
+            v = v.cpu().numpy(); f = f.cpu().numpy()
+            ent = (v, f, np.asarray(mass_properties.mesh_inertia(v, f, 1.0).cpu()))
+            if mesh_cache is not None:
+                mesh_cache[key] = ent
+        else:
+            ent = mesh_cache[key]
+        v, f, J = ent
+        spec["meshes"].append((v, f)); spec["mesh_vgrad"].append(np.zeros_like(v))
+        spec["mesh_id"][s, 1] = len(spec["meshes"]) - 1
+        spec["shape_prm"][s, 1, :2] = latents[s]
+        spec["pose"][s, 1, 4:] = (0.0, -v[:, 1].min() + 2 * Defaults3D.EPSILON, 0.0)
+        Iunit.append(J)
+    T = lambda x: torch.as_tensor(x, dtype=torch.float64)
+    mass, fric, force = T(mass), T(fric), T(force)
+    Iu = T(np.stack(Iunit))
+    one = torch.ones(B, dtype=torch.float64)
+    zero = torch.zeros(B, dtype=torch.float64)
+    params = dict(
+        mass=torch.stack([one, mass], 1),
+        inertia=torch.stack([T(spec["inertia"][:, 0]), mass[:, None, None] * Iu], 1),
+        fric=torch.stack([fric, fric], 1),
+        fext=torch.stack([torch.zeros(B, 6, dtype=torch.float64), torch.stack([zero, zero, zero, force[:, 0], -g * mass, force[:, 1]], 1)], 1))
+    for k in ("mass", "inertia", "fric", "fext"):
+        spec[k] = params[k].detach().numpy()
+    w = BatchWorld3D(spec, params=params, strict_no_penetration=False, max_substeps=4 * run_steps + 64, device=device,
+                     maxc=256, max_cand=8192, max_pc=128)
+    return w
+
+
+def fit_sysid(goal, latents, packed, target, start, run_time=1.0, max_iter=100, lr=None, conv_thresh=1e-5, res=128, log=None):
+    """optim_sysid.py:184-300 for B scenes at once: `goal` in ('mass', 'force', 'friction') is estimated by gradient descent
+    on sum_t |pos_t - pos_t*|^2 of the pushed body, the other two quantities are the targets'.  `target` / `start`: dicts with
+    force [B,2], mass [B], fric [B] (start: only the goal's entry is read).  Learning rates as in the experiment's named
+    configs (:84-100)."""
+    lr = {"mass": 1e-2, "friction": 1e-3, "force": 1e-1}[goal] if lr is None else lr
+    steps = int(math.ceil(run_time / Defaults3D.DT - 1e-9))
+    key = {"mass": "mass", "friction": "fric", "force": "force"}[goal]
+    tv = {k: torch.as_tensor(np.asarray(target[k], np.float64)) for k in ("force", "mass", "fric")}
+    cache = {}
+    with torch.no_grad():
+        wt = push_world(latents, packed, tv["force"], tv["mass"], tv["fric"], steps, res=res, mesh_cache=cache)
+        pos_t = rollout(wt, steps)[0][:, :, 1, 4:].clone()
+    x = torch.tensor(np.asarray(start[key], np.float64), requires_grad=True)
+    hist, last = [], None
+    for e in range(max_iter):
+        if x.grad is not None:
+            x.grad = None
+        cur = dict(tv); cur[key] = x
+        w = push_world(latents, packed, cur["force"], cur["mass"], cur["fric"], steps, res=res, mesh_cache=cache)
+        pos = rollout(w, steps)[0][:, :, 1, 4:]
+        loss = ((pos - pos_t.to(pos)) ** 2).sum(dim=(0, 2))
+        loss.sum().backward()
+        l = loss.detach().cpu().numpy()
+        d = (x.detach() - tv[key]).reshape(len(l), -1).norm(dim=1).numpy()
+        hist.append(dict(iter=e, loss=l.copy(), value=x.detach().numpy().copy(), grad=x.grad.numpy().copy(), dist=d.copy()))
+        if log:
+            log("[%s] iter %3d  mean loss %.3e  mean |x - x*| %.4f  |grad| %.3e" % (goal, e, float(l.mean()), float(d.mean()), float(x.grad.abs().mean())))
+        if last is not None and np.all(np.abs(last - l) < conv_thresh):
+            break
+        with torch.no_grad():
+            x -= lr * x.grad
+        last = l
+    return dict(goal=goal, value=x.detach().numpy().copy(), target=tv[key].numpy().copy(), start=np.asarray(start[key], np.float64), history=hist)
+
+
 def export_trajectory(path, pose, vel, **meta):
     """(T, B, nb, 13) = pose (quaternion wxyz, position) | velocity (angular, linear), as the reference's
     world.trajectory entries (world.py:376-378), one array instead of a python list per scene."""
@@ -261,8 +353,10 @@ def export_trajectory(path, pose, vel, **meta):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace)")
-    ap.add_argument("what", choices=["sphere", "inertia"])
+    ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace, system_identification/optim_sysid)")
+    ap.add_argument("what", choices=["sphere", "inertia", "sysid"])
+    ap.add_argument("--goal", default="mass", choices=["mass", "force", "friction"])
+    ap.add_argument("--run-time", type=float, default=1.0)
     ap.add_argument("--scenes", type=int, default=64)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
@@ -279,6 +373,17 @@ def main(argv=None):
         print(radius_error_table(res))
         if a.out:
             np.savez_compressed(a.out, **{k.replace(" ", "_").replace(",", ""): v["radius"] for k, v in res.items()}, target=target, start=start)
+    elif a.what == "sysid":
+        # optim_sysid.py:184-220: a random latent, push, mass and friction per scene; the goal's start value is drawn anew
+        from . import igr
+        packed = igr.pack_weights(*scenes.geometric_init_weights(a.seed, 0.5))
+        uni = lambda lo, hi, *sh: lo + (hi - lo) * r.random((a.scenes,) + sh)
+        lat = 0.1 * r.standard_normal((a.scenes, 2))
+        target = dict(force=uni(2.0, 5.0, 2), mass=uni(0.9, 1.1), fric=uni(0.01, 0.25))
+        start = dict(force=uni(2.0, 5.0, 2), mass=uni(0.9, 1.1), fric=uni(0.01, 0.25))
+        res = fit_sysid(a.goal, lat, packed, target, start, run_time=a.run_time, max_iter=a.iters, log=print)
+        d0, d1 = np.abs(res["start"] - res["target"]).reshape(a.scenes, -1).max(1), np.abs(res["value"] - res["target"]).reshape(a.scenes, -1).max(1)
+        print("%s: |x - x*| start mean %.4f -> final mean %.4f (max %.4f), %d scenes" % (a.goal, d0.mean(), d1.mean(), d1.max(), a.scenes))
     else:
         from . import igr
         packed = igr.pack_weights(*scenes.geometric_init_weights(a.seed, 0.5))

@@ -106,7 +106,10 @@ class Body3D:
         vt = getattr(self, "verts_t", None)
         if vt is not None and vt.requires_grad:       # differentiable like the reference's get_ang_inertia (autograd there)
             return mass_properties.mesh_inertia_diff(vt, torch.as_tensor(self.faces_np), mass).cpu()
-        return mass_properties.mesh_inertia(self.verts_np, self.faces_np, float(torch.as_tensor(mass).detach())).cpu()
+        m = torch.as_tensor(mass)
+        if m.requires_grad:      # the integrals are linear in the mass (system identification: d / d mass through the inertia)
+            return mass_properties.mesh_inertia(self.verts_np, self.faces_np, 1.0).cpu() * m.cpu().to(torch.float64)
+        return mass_properties.mesh_inertia(self.verts_np, self.faces_np, float(m.detach())).cpu()
 
 
 class SDFBox(Body3D):

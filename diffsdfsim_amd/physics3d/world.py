@@ -266,10 +266,26 @@ class World3D(BatchWorld3D):
         self._pull_bodies()
         E = self.engine
         self._start = (self._t, self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}, self._n_nodes)
+        n0, t0 = int(E.get("nsub")[0]), self._t
         had = bool(BatchWorld3D.step(self, fixed_dt)[0])
         self._t = float(self.engine.get("t")[0])
         self._sync_bodies()
-        # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-377 appends them; contacts by value
+        # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-377 appends them, one entry per ACCEPTED
+        # sub-step (step(fixed_dt=True) loops step_dt until the full dt has passed, world.py:119-139).  The sub-steps inside
+        # one outer step are read back from the tape (values: only the state at the end of the call is connected to the graph)
+        n1 = int(E.get("nsub")[0])
+        if n1 - n0 > 1 and n1 <= int(E.W.max_sub):
+            tp, tv, tdt = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_dt")
+            tnc, tb, tg = E.get("tp_nc"), E.get("tp_body"), E.get("tp_geom")
+            t = t0
+            for j in range(n0, n1 - 1):          # the state after sub-step j = the start of sub-step j + 1
+                t += float(tdt[j, 0])
+                cs = []
+                for c in range(int(tnc[j + 1, 0])):
+                    g_, b_ = tg[j + 1, 0], tb[j + 1, 0]
+                    tt = lambda a: torch.tensor(a.copy())
+                    cs.append(((tt(g_[0:3, c]), tt(g_[3:6, c]), tt(g_[6:9, c]), tt(g_[9, c])), int(b_[0, c]), int(b_[1, c])))
+                self.trajectory.append((t, torch.tensor(tp[j + 1, 0].reshape(-1)), torch.tensor(tv[j + 1, 0].reshape(-1)), cs, None))
         self.trajectory.append((self._t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), self.contacts, None))
         return had
 

@@ -145,7 +145,56 @@ def run(name, make, run_time, seed=0, radius=0.5, latent0=(0.05, -0.08), fixed=(
     print(name, "steps", T, "nc", nc.tolist(), "loss", float(loss), "d loss/d latent", g.numpy(), "%.0f s" % (time.time() - t0))
 
 
+def run_push(name="rollout_igr_push", nsteps=8, seed=0, radius=0.5, latent0=(0.05, -0.03), force0=(3.0, 2.5), mass0=1.0, fric0=0.1):
+    """The scene of experiments/system_identification/optim_sysid.py:104-131 (`make_world`: floor, a neural-SDF body of scale 1
+    set down on it, gravity, a constant push along x and z, strict_no_penetration=False, fric_dirs=8) with an analytic floor
+    mesh, stepped `nsteps` times; loss = sum_t |pos_t - target_t|^2 against a fixed target line (:246-250) and its gradient
+    w.r.t. the push, the body's mass and the friction coefficient (shared by both bodies, as there) from torch.autograd."""
+    from sdf_physics.physics3d.forces import ExternalForce3D
+    from sdf_physics.physics3d.utils import Defaults3D
+    t0 = time.time()
+    net, _Ws, _bs = fake_igr.seeded_net(seed, radius)
+    latent = torch.tensor(latent0, dtype=torch.float64)
+    force = torch.tensor(force0, dtype=torch.float64, requires_grad=True)
+    mass = torch.tensor([mass0], dtype=torch.float64, requires_grad=True)
+    fric = torch.tensor([fric0], dtype=torch.float64, requires_grad=True)
+
+    def force_func(t):
+        fv = get_tensor([0, 0, 0, 0, 0, 0])
+        fv[[-3, -1]] = force
+        return fv
+    floor = SDFBox([0, -.5, 0], [20, 1, 20], fric_coeff=fric, restitution=0.0, custom_mesh=True, custom_inertia=True)
+    obj = SDF3D([0, 0, 0], scale=1, sdf_func=decode_igr(net), params=[latent], mass=mass, fric_coeff=fric, restitution=0.0)
+    obj_pos = get_tensor([0, 0, 0])
+    obj_pos[1] = -obj.verts.min(dim=0)[0][1] + 2 * Defaults3D.EPSILON
+    obj.set_p(torch.cat([obj_pos.new_ones(1), obj_pos.new_zeros(3), obj_pos]))
+    obj.add_force(Gravity3D())
+    obj.add_force(ExternalForce3D(force_func))
+    w = World3D([floor, obj], [TotalConstraint3D(floor)], time_of_contact_diff=True, strict_no_penetration=False, fric_dirs=8)
+    print(name, "world built in %.1f s; body mesh" % (time.time() - t0), len(obj.verts), len(obj.faces), "contacts", len(w.contacts))
+    d = dict(igr_seed=seed, igr_radius=radius, latent=np.array(latent0), force=np.array(force0), mass=mass0, fric=fric0, nsteps=nsteps,
+             pose0=np.stack([floor.p.detach().numpy(), obj.p.detach().numpy()]), meshsize_1=np.array([len(obj.verts), len(obj.faces)]),
+             verts_1=obj.verts.detach().numpy(), faces_1=obj.faces.numpy().astype(np.int32), dt=w.dt)
+    target = np.stack([obj.p.detach().numpy()[4:] + np.array([0.02, 0.0, 0.015]) * (k + 1) for k in range(nsteps)])
+    loss = 0.0
+    for k in range(nsteps):
+        w.step(fixed_dt=True)
+        loss = loss + ((get_tensor(target[k].tolist()) - obj.pos) ** 2).sum()
+        print("  t=%.4f nc=%d" % (w.t, len(w.contacts)), flush=True)
+    d["target"] = target
+    d["traj_t"] = np.array([float(e[0]) for e in w.trajectory])
+    d["traj_p"] = np.stack([e[1].detach().numpy().reshape(2, 7) for e in w.trajectory])
+    d["traj_v"] = np.stack([e[2].detach().numpy().reshape(2, 6) for e in w.trajectory])
+    d["traj_nc"] = np.array([len(e[3]) for e in w.trajectory], np.int32)
+    gf, gm, gc = torch.autograd.grad(loss, [force, mass, fric])
+    d["loss"], d["grad_force"], d["grad_mass"], d["grad_fric"] = float(loss), gf.numpy(), gm.numpy(), gc.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "sub-steps", len(w.trajectory), "nc", d["traj_nc"].tolist(), "loss", float(loss), "grads", gf.numpy(), gm.numpy(), gc.numpy(),
+          "%.0f s" % (time.time() - t0))
+
+
 CASES = {
+    "rollout_igr_push": (None, None),
     "rollout_igr_demo": (demo_world, dict(run_time=1.1)),
     "rollout_igr_small": (small_world, dict(run_time=0.4, fixed=(0,), target=(0.0, 1.0, 0.0))),
 }
@@ -155,4 +204,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for name in (sys.argv[1:] or list(CASES)):
         make, kw = CASES[name]
-        run(name, make, **kw)
+        if make is None:
+            run_push(name)
+        else:
+            run(name, make, **kw)

@@ -69,3 +69,22 @@ def test_inertia_fitting_gradient_reaches_the_latent_code():
     h = res["history"]
     assert np.isfinite(h[0]["grad"]).all() and np.abs(h[0]["grad"]).max() > 0
     assert h[-1]["loss"].sum() < h[0]["loss"].sum(), ([x["loss"] for x in h])
+
+
+@pytest.mark.parametrize("goal", ["mass", "force", "friction"])
+def test_system_identification_of_a_pushed_neural_body(goal):
+    """experiments/system_identification/optim_sysid.py:104-300 for three scenes at once (short horizon, coarse mesh): a neural
+    SDF body pushed along the floor; the gradient of sum_t |pos_t - pos_t*|^2 reaches the goal (mass through inertia, gravity
+    and the LCP's mass blocks; the push through the external force; the friction coefficient through the cone rows), the loss
+    falls and the estimate moves towards the target."""
+    from diffsdfsim_amd import experiments as X, igr, scenes
+    packed = igr.pack_weights(*scenes.geometric_init_weights(0, 0.5))
+    lat = np.array([[0.05, -0.03], [-0.04, 0.06], [0.0, 0.02]])
+    target = dict(force=np.array([[3.0, 2.5], [4.0, 2.0], [2.5, 3.5]]), mass=np.array([1.0, 0.95, 1.05]), fric=np.array([0.1, 0.2, 0.15]))
+    start = dict(force=target["force"] + np.array([[0.8, -0.6], [-0.7, 0.9], [0.6, 0.5]]), mass=target["mass"] + np.array([0.08, -0.07, 0.06]),
+                 fric=target["fric"] + np.array([0.06, -0.08, 0.07]))
+    res = X.fit_sysid(goal, lat, packed, target, start, run_time=0.4, max_iter=6, res=48)
+    h = res["history"]
+    assert np.isfinite(h[0]["grad"]).all() and np.abs(h[0]["grad"]).min() > 0
+    assert h[-1]["loss"].sum() < h[0]["loss"].sum(), [x["loss"].sum() for x in h]
+    assert h[-1]["dist"].mean() < h[0]["dist"].mean(), (h[0]["dist"], h[-1]["dist"])

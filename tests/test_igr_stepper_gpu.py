@@ -99,3 +99,43 @@ def test_latent_gradient_matches_reference_autograd(name):
     loss.backward()
     got, want = latent.grad.cpu().numpy(), g["grad_latent"]
     assert np.abs(got - want).max() < 1e-5 * np.abs(want).max(), (got, want)
+
+
+def test_system_identification_scene_gradients_match_reference_autograd():
+    """The scene of experiments/system_identification/optim_sysid.py:104-131 -- a neural-SDF body set down on the floor and
+    pushed along it, strict_no_penetration=False -- through the public surface: eight outer steps (14 sub-steps with dt
+    halving), the same trajectory as the reference, and d sum_t |pos_t - target_t|^2 / d (push, mass, friction coefficient)
+    equal to the reference's autograd values: the mass through inertia, gravity and the LCP's mass blocks, the friction
+    coefficient (one tensor for both bodies) through the cone rows, the push through the external force."""
+    import torch
+    from diffsdfsim_amd.physics3d import ExternalForce3D, Gravity3D, SDF3D, SDFBox, TotalConstraint3D, World3D
+    from diffsdfsim_amd.physics3d.utils import decode_igr, get_tensor
+    g = R.load_rollout("rollout_igr_push")
+    net = H.torch_network(g)
+    latent = torch.tensor(g["latent"], dtype=torch.float64)
+    force = torch.tensor(g["force"], dtype=torch.float64, requires_grad=True)
+    mass = torch.tensor([float(g["mass"])], dtype=torch.float64, requires_grad=True)
+    fric = torch.tensor([float(g["fric"])], dtype=torch.float64, requires_grad=True)
+
+    def force_func(t):
+        fv = get_tensor([0, 0, 0, 0, 0, 0])
+        idx = torch.tensor([3, 5])
+        return fv.index_put((idx,), force.to(fv))
+    floor = SDFBox([0, -.5, 0], [20, 1, 20], fric_coeff=fric, restitution=0.0, custom_mesh=True, custom_inertia=True)
+    obj = SDF3D([0, 0, 0], scale=1, sdf_func=decode_igr(net), params=[latent], mass=mass, fric_coeff=fric, restitution=0.0)
+    assert (len(obj.verts_np), len(obj.faces_np)) == tuple(g["meshsize_1"])
+    obj.set_p(torch.tensor(g["pose0"][1], dtype=torch.float64))
+    obj.add_force(Gravity3D())
+    obj.add_force(ExternalForce3D(force_func))
+    w = World3D([floor, obj], [TotalConstraint3D(floor)], time_of_contact_diff=True, strict_no_penetration=False, fric_dirs=8)
+    loss = 0.0
+    for k in range(int(g["nsteps"])):
+        w.step(fixed_dt=True)
+        loss = loss + ((torch.tensor(g["target"][k], device=obj.pos.device) - obj.pos) ** 2).sum()
+    assert len(w.trajectory) == len(g["traj_t"])
+    assert np.abs(obj.p.detach().cpu().numpy() - g["traj_p"][-1][1]).max() < 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-7
+    loss.backward()
+    for name, t in (("grad_force", force), ("grad_mass", mass), ("grad_fric", fric)):
+        got, want = t.grad.cpu().numpy(), g[name]
+        assert np.abs(got - want).max() < 1e-5 * np.abs(want).max(), (name, got, want)
