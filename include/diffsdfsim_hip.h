@@ -387,6 +387,27 @@ int dss_mc_emit(const double *phi, int n0, int n1, int n2, double iso, const int
 int dss_meshsdf_backward(int shape_type, const double *unit_prm, const double *unit_verts, const double *grad_verts, int nv,
                          double *grad_prm, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * R18: analytic 2-D contacts -- replaces DiffContactHandler.__call__ (lcp_physics/physics/contacts.py:55-215; the
+ * reference's 2-D world of BASELINE configs[0]) for a batch of body pairs, with its vector-Jacobian product (the reference
+ * gets that from autograd through the same arithmetic).  A body is a circle (kind 0) or a convex polygon (kind 1, nv <=
+ * DSS_C2D_MAXV vertices about its centroid in world orientation, clockwise in the reference's y-down frame: bodies.py
+ * Hull.verts).  Arrays are [2][npairs]... : body 1 of every pair, then body 2.
+ *   kind, nv [2][P]; pos [2][P][2]; rad [2][P] (circles); verts [2][P][maxv][2];
+ *   sat_in / sat_out [2][P]: Hull.last_sat_idx, the edge the separating-axis loops start from (state of the body:
+ *     contacts.py:124-131, 153-158, 236) before / after the call;
+ *   count [P] in {0, 1, 2}; out [P][2][7] = normal (2, from body 2 to body 1), p1 (2, offset from body 1's position),
+ *     p2 (2, from body 2's), penetration -- the tuple the reference appends to world.contacts (contacts.py:208-209).
+ *   backward: gout [P][2][7] (rows >= count ignored) -> g_pos [2][P][2], g_rad [2][P], g_verts [2][P][maxv][2], with the
+ *     sat_in the forward started from (the branch decisions are taken on values, as the reference takes them on .item()). */
+#define DSS_C2D_MAXV 8
+int dss_contacts2d_forward(int npairs, int maxv, const int *kind, const int *nv, const double *pos, const double *rad,
+                           const double *verts, const int *sat_in, double eps, int *sat_out, int *count, double *out,
+                           void *stream);
+int dss_contacts2d_backward(int npairs, int maxv, const int *kind, const int *nv, const double *pos, const double *rad,
+                            const double *verts, const int *sat_in, double eps, const double *gout, double *g_pos,
+                            double *g_rad, double *g_verts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

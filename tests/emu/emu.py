@@ -200,3 +200,28 @@ def mesh_inertia_backward(verts, faces, mass, gJ):
     rc = L.dss_mesh_inertia_backward(_p(V), _p(F), len(V), len(F), ctypes.c_double(mass), _p(g), _p(out), None)
     assert rc == 0
     return out
+
+
+def contacts2d_forward(kind, nv, pos, rad, verts, sat_in, eps):
+    """dss_contacts2d_forward on host arrays: kind / nv / sat_in [2][P], pos [2][P][2], rad [2][P], verts [2][P][maxv][2]."""
+    L = lib()
+    kind, nv, sat_in = (_c(x, np.int32) for x in (kind, nv, sat_in))
+    pos, rad, verts = (_c(x) for x in (pos, rad, verts))
+    P, maxv = pos.shape[1], verts.shape[2]
+    sat_out = np.zeros((2, P), np.int32); count = np.zeros(P, np.int32); out = np.zeros((P, 2, 7))
+    rc = L.dss_contacts2d_forward(P, maxv, _p(kind), _p(nv), _p(pos), _p(rad), _p(verts), _p(sat_in), ctypes.c_double(eps),
+                                  _p(sat_out), _p(count), _p(out), None)
+    assert rc == 0, rc
+    return out, count, sat_out
+
+
+def contacts2d_backward(kind, nv, pos, rad, verts, sat_in, eps, gout):
+    L = lib()
+    kind, nv, sat_in = (_c(x, np.int32) for x in (kind, nv, sat_in))
+    pos, rad, verts, gout = (_c(x) for x in (pos, rad, verts, gout))
+    P, maxv = pos.shape[1], verts.shape[2]
+    g_pos, g_rad, g_verts = np.zeros_like(pos), np.zeros_like(rad), np.zeros_like(verts)
+    rc = L.dss_contacts2d_backward(P, maxv, _p(kind), _p(nv), _p(pos), _p(rad), _p(verts), _p(sat_in), ctypes.c_double(eps),
+                                   _p(gout), _p(g_pos), _p(g_rad), _p(g_verts), None)
+    assert rc == 0, rc
+    return g_pos, g_rad, g_verts

@@ -1,0 +1,106 @@
+"""GPU: the 2-D analytic contact handler (csrc/contacts2d.hip through the C ABI and
+diffsdfsim_amd.physics2d) against the golden vectors recorded from the reference's DiffContactHandler."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def load(dev):
+    g = np.load(os.path.join(GOLDEN, "contacts2d.npz"))
+    sw = lambda a, dt: torch.as_tensor(np.ascontiguousarray(np.swapaxes(a, 0, 1)), dtype=dt, device=dev)      # noqa: E731
+    a = dict(pos=sw(g["pos"], torch.float64), rad=sw(g["rad"], torch.float64), verts=sw(g["verts"], torch.float64),
+             kind=sw(g["kind"], torch.int32), nv=sw(g["nv"], torch.int32), sat_in=sw(g["sat_in"], torch.int32), eps=float(g["eps"]))
+    return g, a
+
+
+def test_contacts_and_gradients_match_the_reference_handler():
+    from diffsdfsim_amd.physics2d import contacts2d
+    g, a = load("cuda:0")
+    for k in ("pos", "rad", "verts"):
+        a[k].requires_grad_(True)
+    out, count, sat_out = contacts2d(**a)
+    assert (count.cpu().numpy() == g["count"]).all()
+    assert (sat_out.cpu().numpy().T == g["sat_out"]).all()
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 1e-12
+    (out * torch.as_tensor(g["gout"], device=out.device)).sum().backward()
+    for mine, ref in ((a["pos"].grad, g["g_pos"]), (a["rad"].grad, g["g_rad"]), (a["verts"].grad, g["g_verts"])):
+        ref = np.swapaxes(ref, 0, 1)
+        assert np.abs(mine.cpu().numpy() - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def test_one_pair_at_a_time_equals_the_batch():
+    from diffsdfsim_amd.physics2d import contacts2d
+    g, a = load("cuda:0")
+    out, count, sat_out = contacts2d(**a)
+    for i in (0, 57, 131, 222, 399):
+        one = {k: (v[:, i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in a.items()}
+        o1, c1, s1 = contacts2d(**one)
+        assert torch.equal(o1[0], out[i]) and int(c1[0]) == int(count[i]) and torch.equal(s1[:, 0], sat_out[:, i])
+
+
+def test_handler_appends_the_reference_tuples_for_world_bodies_on_the_host():
+    """The handler as the reference's world calls it (`contact_callback(args, geom1, geom2)`, world.py:396-399), with bodies
+    whose tensors live on the host: geometry goes to the device, tuples and gradients come back."""
+    from diffsdfsim_amd.physics2d import make_handler
+    g = np.load(os.path.join(GOLDEN, "contacts2d.npz"))
+
+    class Obj:
+        pass
+    for i in list(np.nonzero(g["count"] == 2)[0][:3]) + list(np.nonzero((g["count"] == 1) & (g["kind"][:, 0] == 1) & (g["kind"][:, 1] == 0))[0][:3]):
+        bodies, leaves = [], []
+        for s in range(2):
+            b = Obj()
+            b.pos = torch.tensor(g["pos"][i, s], requires_grad=True)
+            leaves.append(b.pos)
+            if g["kind"][i, s] == 0:
+                b.rad = torch.tensor(g["rad"][i, s], requires_grad=True)
+                leaves.append(b.rad)
+            else:
+                b.verts = [torch.tensor(v, requires_grad=True) for v in g["verts"][i, s, :g["nv"][i, s]]]
+                b.last_sat_idx = int(g["sat_in"][i, s])
+                leaves += b.verts
+            bodies.append(b)
+        w = Obj(); w.bodies, w.eps, w.contacts = bodies, float(g["eps"]), []
+        g1, g2 = Obj(), Obj()
+        g1.body, g2.body, g1.no_contact, g2.no_contact = 0, 1, set(), set()
+        make_handler(device="cuda:0")()([w], g1, g2)
+        assert len(w.contacts) == int(g["count"][i])
+        loss = 0.0
+        for q, (c, i1, i2) in enumerate(w.contacts):
+            assert (i1, i2) == (0, 1) and c[0].device.type == "cpu"
+            flat = torch.cat([c[0], c[1], c[2], c[3].reshape(1)])
+            assert np.abs(flat.detach().numpy() - g["out"][i, q]).max() < 1e-12
+            loss = loss + (flat * torch.tensor(g["gout"][i, q])).sum()
+        loss.backward()
+        for s, b in enumerate(bodies):
+            assert np.abs(b.pos.grad.numpy() - g["g_pos"][i, s]).max() < 1e-9
+            if hasattr(b, "verts"):
+                assert b.last_sat_idx == int(g["sat_out"][i, s])
+                got = np.stack([v.grad.numpy() if v.grad is not None else np.zeros(2) for v in b.verts])
+                assert np.abs(got - g["g_verts"][i, s, :len(b.verts)]).max() < 1e-9
+            else:
+                assert abs(float(b.rad.grad) - g["g_rad"][i, s]) < 1e-9
+        g2.no_contact.add(g1)
+        w.contacts = []
+        make_handler(device="cuda:0")()([w], g1, g2)
+        assert w.contacts == []
+
+
+def test_limits_and_empty_batch():
+    from diffsdfsim_amd import _lib
+    from diffsdfsim_amd.physics2d import contacts2d
+    dev = "cuda:0"
+    z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)      # noqa: E731
+    out, count, sat = contacts2d(z(2, 0, 2), z(2, 0), z(2, 0, 4, 2), z(2, 0, dt=torch.int32), z(2, 0, dt=torch.int32), z(2, 0, dt=torch.int32), 0.1)
+    assert out.shape == (0, 2, 7) and count.numel() == 0
+    with pytest.raises(_lib.HipLibraryError):
+        contacts2d(z(2, 1, 2), z(2, 1), z(2, 1, 9, 2), z(2, 1, dt=torch.int32), z(2, 1, dt=torch.int32), z(2, 1, dt=torch.int32), 0.1)
+    with pytest.raises(_lib.HipLibraryError):
+        contacts2d(z(2, 1, 2).cpu(), z(2, 1).cpu(), z(2, 1, 4, 2).cpu(), z(2, 1, dt=torch.int32).cpu(), z(2, 1, dt=torch.int32).cpu(),
+                   z(2, 1, dt=torch.int32).cpu(), 0.1)

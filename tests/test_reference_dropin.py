@@ -74,6 +74,89 @@ def test_reference_2d_world_on_the_builds_lcp_kernels():
     assert abs(float(rad.grad) - float(g["drad"])) < 1e-6 * abs(float(g["drad"])), (float(rad.grad), float(g["drad"]))
 
 
+def emu_contact_handler():
+    """The product's handler class (diffsdfsim_amd/physics2d) over the emulator build of csrc/contacts2d.hip."""
+    from diffsdfsim_amd.physics2d import make_handler
+    t = torch.as_tensor
+
+    def fwd(kind, nv, pos, rad, verts, sat_in, eps):
+        out, count, sat_out = emu.contacts2d_forward(kind.numpy(), nv.numpy(), pos.detach().numpy(), rad.detach().numpy(),
+                                                     verts.detach().numpy(), sat_in.numpy(), eps)
+        return t(out), t(count), t(sat_out)
+
+    def bwd(kind, nv, pos, rad, verts, sat_in, eps, gout):
+        return tuple(t(x) for x in emu.contacts2d_backward(kind.numpy(), nv.numpy(), pos.numpy(), rad.numpy(), verts.numpy(),
+                                                           sat_in.numpy(), eps, gout.numpy()))
+    return make_handler((fwd, bwd))
+
+
+def test_reference_2d_world_on_the_builds_contact_and_lcp_kernels():
+    """Config 1 with BOTH of its path functions replaced: the analytic contact handler (R18, the `contact_callback=` seam,
+    lcp_physics/physics/world.py:44-52) and the LCP (B1).  Same golden, same tolerances."""
+    from oracle import refshim
+    refshim.install()
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import TotalConstraint
+    from lcp_physics.physics.forces import Gravity
+    from lcp_physics.physics.world import World
+
+    g = np.load(os.path.join(GOLDEN, "config1_lcp.npz"))
+    rad = torch.tensor(20.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.5, fric_coeff=0.9)
+    ball = Circle([500, 480], rad, vel=[0, 30, 0], restitution=0.5, fric_coeff=0.9)
+    ball.add_force(Gravity(g=100))
+    calls = []
+    w = World([floor, ball], [TotalConstraint(floor)], dt=1.0 / 30, contact_callback=emu_contact_handler())
+    w.engine.lcp_solver = kernel_lcp_function(calls)
+    for _ in range(50):
+        w.step()
+    loss = (ball.pos ** 2).sum()
+    loss.backward()
+    assert len(calls) == int(g["n_calls"]) and len(w.trajectory) == int(g["n_substeps"])
+    final_p = torch.cat([b.p for b in (floor, ball)]).detach().numpy()
+    assert np.abs(final_p - g["final_p"]).max() < 1e-8 * np.abs(g["final_p"]).max()
+    assert abs(float(loss) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
+    assert abs(float(rad.grad) - float(g["drad"])) < 1e-6 * abs(float(g["drad"])), (float(rad.grad), float(g["drad"]))
+
+
+def test_reference_2d_world_polygon_scene_with_the_builds_contact_handler():
+    """Polygon against polygon and circle against polygon in one world (a tilted box and a ball dropped on a floor slab, the
+    box landing on a corner and tipping onto its face, the ball rolling into it): the reference's world stepped once with its own DiffContactHandler
+    and once with the build's, its own LCP in both.  Contact pairs per step, final poses and d loss / d (box width, ball
+    radius) agree."""
+    from oracle import refshim
+    refshim.install()
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import TotalConstraint
+    from lcp_physics.physics.forces import Gravity
+    from lcp_physics.physics.world import World
+
+    def run(handler):
+        wd = torch.tensor(80.0, dtype=torch.double, requires_grad=True)
+        rad = torch.tensor(25.0, dtype=torch.double, requires_grad=True)
+        floor = Rect([500, 600], [1000, 50], restitution=0.2, fric_coeff=0.6)
+        box = Rect([0.3, 420, 520], torch.stack([wd, wd.new_tensor(50.0)]), restitution=0.2, fric_coeff=0.6)
+        ball = Circle([560, 500], rad, vel=[0, -150, 0], restitution=0.2, fric_coeff=0.6)
+        for b in (box, ball):
+            b.add_force(Gravity(g=100))
+        kw = {} if handler is None else {"contact_callback": handler}
+        w = World([floor, box, ball], [TotalConstraint(floor)], dt=1.0 / 30, **kw)
+        counts = []
+        for _ in range(60):
+            w.step()
+            counts.append([(c[1], c[2]) for c in w.contacts])
+        loss = (box.p ** 2).sum() + (ball.pos ** 2).sum()
+        gw, gr = torch.autograd.grad(loss, [wd, rad])
+        return counts, torch.cat([b.p for b in (floor, box, ball)]).detach().numpy(), float(gw), float(gr)
+
+    c0, p0, gw0, gr0 = run(None)
+    c1, p1, gw1, gr1 = run(emu_contact_handler())
+    assert c0 == c1 and {(0, 1), (0, 2), (1, 2)} <= {pr for step in c0 for pr in step}     # box / floor, ball / floor, ball / box
+    assert max(len(step) for step in c0) >= 3
+    assert np.abs(p0 - p1).max() < 1e-9 * np.abs(p0).max()
+    assert abs(gw0 - gw1) < 1e-7 * max(1.0, abs(gw0)) and abs(gr0 - gr1) < 1e-7 * max(1.0, abs(gr0)), (gw0, gw1, gr0, gr1)
+
+
 def test_reference_3d_world_on_the_builds_lcp_kernels():
     """The same substitution under the reference's World3D (FWContactHandler, PdipmEngine): config 2's scene, one sphere
     dropped on the floor, 24 steps with time-of-contact differentials, against the rollout recorded with the
