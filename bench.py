@@ -451,6 +451,11 @@ def main():
                 "reference_lapack_lcp_s_per_scene": {"value": 0.078, "where": "the reference's own torch/LAPACK LCPFunction fwd+bwd at nineq=560 "
                                                      "on the 8-vCPU build container (SURVEY.md section 6); the plain-C port here is several "
                                                      "times slower than that"},
+                "reference_whole_step_s_per_scene": {"value": 0.45, "where": "the reference itself (imported, torch CPU, float64), floor + 7-box stack with "
+                                                     "its own level-set meshes, 56 contacts, 3 steps forward + backward on the 8-vCPU build "
+                                                     "container: 2.2 scene-steps/s (SURVEY.md section 6).  Not timed on this host (the reference "
+                                                     "cannot travel); quoted so that the detection half of a CPU step has a size: about 0.37 s "
+                                                     "per scene-step outside the LCP"},
                 "sample": "dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, the reference's algorithm, unblocked LU) on the operands of %d "
                           "median scenes of this batch (nineq=%d), scaled to %d scenes" % (ns, nineq, B)}
         else:
