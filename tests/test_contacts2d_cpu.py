@@ -44,3 +44,23 @@ def test_every_branch_of_the_handler_is_in_the_golden_set():
     m = np.array([k in ((0, 1), (1, 0)) for k in kinds]) & (g["count"] == 1)
     deep = [i for i in np.nonzero(m)[0] if g["out"][i, 0, 6] > g["rad"][i].max() + 1e-9]
     assert len(deep) >= 5
+
+
+def test_numpy_restatement_with_the_gjk_walk_is_pinned_by_the_same_goldens():
+    """oracle/contacts2d_oracle.py follows the reference's walk (GJK from vertex 0) where the kernels search edge by edge; both
+    must land on what the reference recorded."""
+    from oracle import contacts2d_oracle as O
+    g, a = load()
+    out, count, sat_out = O.contacts2d(**a)
+    assert (count == g["count"]).all() and (sat_out.T == g["sat_out"]).all()
+    assert np.abs(out - g["out"]).max() < 1e-11
+
+
+def test_kernels_and_restatement_agree_on_fresh_random_pairs():
+    from oracle import contacts2d_oracle as O
+    a = O.random_pairs(np.random.default_rng(2024), 300)
+    ref = O.contacts2d(eps=0.1, **a)
+    got = emu.contacts2d_forward(eps=0.1, **a)
+    assert (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
+    assert np.abs(got[0] - ref[0]).max() < 1e-11
+    assert (ref[1] == 2).sum() > 10 and (ref[1] == 0).sum() > 30

@@ -104,3 +104,62 @@ def test_limits_and_empty_batch():
     with pytest.raises(_lib.HipLibraryError):
         contacts2d(z(2, 1, 2).cpu(), z(2, 1).cpu(), z(2, 1, 4, 2).cpu(), z(2, 1, dt=torch.int32).cpu(), z(2, 1, dt=torch.int32).cpu(),
                    z(2, 1, dt=torch.int32).cpu(), 0.1)
+
+
+def _to_dev(a, dev="cuda:0"):
+    t = {}
+    for k, v in a.items():
+        t[k] = torch.as_tensor(v, device=dev, dtype=torch.float64 if v.dtype.kind == "f" else torch.int32).contiguous()
+    return t
+
+
+def test_fresh_random_pairs_against_the_numpy_restatement():
+    """4000 pairs no golden covers: the device kernels (closest feature found edge by edge) against the restatement that
+    walks GJK as the reference does (oracle/contacts2d_oracle.py, pinned by the goldens)."""
+    from diffsdfsim_amd.physics2d import contacts2d
+    from oracle import contacts2d_oracle as O
+    a = O.random_pairs(np.random.default_rng(99), 4000)
+    ref_out, ref_count, ref_sat = O.contacts2d(eps=0.1, **a)
+    out, count, sat = contacts2d(eps=0.1, **_to_dev(a))
+    assert (count.cpu().numpy() == ref_count).all() and (sat.cpu().numpy() == ref_sat).all()
+    assert np.abs(out.cpu().numpy() - ref_out).max() < 1e-11
+    assert all((ref_count == c).sum() > 100 for c in (0, 1, 2))
+
+
+def test_vector_jacobian_product_against_central_differences_of_the_restatement():
+    """d <gout, contacts> along a random direction of all coordinates: the backward kernel against central differences of the
+    numpy restatement, on the pairs whose feature decisions do not change within the difference step."""
+    from diffsdfsim_amd.physics2d import contacts2d
+    from oracle import contacts2d_oracle as O
+    rng = np.random.default_rng(5)
+    a = O.random_pairs(rng, 600)
+    t = _to_dev(a)
+    for k in ("pos", "rad", "verts"):
+        t[k].requires_grad_(True)
+    out, count, _ = contacts2d(eps=0.1, **t)
+    gout = rng.normal(size=out.shape)
+    (out * torch.as_tensor(gout, device=out.device)).sum().backward()
+    mask_v = (np.arange(a["verts"].shape[2])[None, None, :, None] < a["nv"][:, :, None, None])
+    d = {"pos": rng.normal(size=a["pos"].shape), "rad": rng.normal(size=a["rad"].shape) * (a["kind"] == 0),
+         "verts": rng.normal(size=a["verts"].shape) * mask_v}
+    ad = sum((t[k].grad.cpu().numpy() * d[k]).reshape(2, 600, -1).sum((0, 2)) for k in d)      # per pair
+
+    def f(h):
+        b = dict(a)
+        for k in d:
+            b[k] = a[k] + h * d[k]
+        o, c, s = O.contacts2d(eps=0.1, **b)
+        return (o * gout).sum((1, 2)), c, s
+    checked = 0
+    (fp, cp, sp), (fm, cm, sm) = f(1e-6), f(-1e-6)
+    (fp2, cp2, _), (fm2, cm2, _) = f(2e-6), f(-2e-6)
+    cnt = count.cpu().numpy()
+    for p in range(600):
+        if cnt[p] == 0 or not (cp[p] == cm[p] == cp2[p] == cm2[p] == cnt[p]) or not (sp[:, p] == sm[:, p]).all():
+            continue
+        fd1, fd2 = (fp[p] - fm[p]) / 2e-6, (fp2[p] - fm2[p]) / 4e-6
+        if abs(fd1 - fd2) > 1e-5 * max(1.0, abs(fd1)):      # a feature switch inside the step
+            continue
+        assert abs(fd1 - ad[p]) < 2e-5 * max(1.0, abs(fd1)), (p, fd1, ad[p], a["kind"][:, p])
+        checked += 1
+    assert checked > 250
