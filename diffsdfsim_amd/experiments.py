@@ -14,6 +14,9 @@ inertia fitting  (experiments/inertia_fitting/optim_shapespace.py)
     spin_world(latents, torque_dirs, net)         one neural-SDF body per scene, translation locked (X/Y/Z constraints), torque for
                                                   t < 0.3 (:71-92); inertia from the body's level-set mesh, differentiable w.r.t. the latent
     fit_inertia_latent(...)                       the loop of :136-250: loss = |v_T - v_T*|^2 + reg |latent|^2
+inertia fitting of primitives  (experiments/inertia_fitting/optim_primitives.py)
+    primitive_spin_world(kind, dims)              the same scene for an SDFBox / SDFSphere / SDFCylinder per row of dimensions (:95-115)
+    fit_inertia_primitive(kind, ...)              the loop of :160-240 (Adam, dimensions clamped to [0.5, 2])
 
 system identification  (experiments/system_identification/optim_sysid.py)
     push_world(latents, packed, force, mass, fric, ...)   the floor and a neural-SDF body pushed along it (:104-131), per scene its own
@@ -22,6 +25,7 @@ system identification  (experiments/system_identification/optim_sysid.py)
 
     python -m diffsdfsim_amd.experiments sphere --scenes 64 --iters 100
     python -m diffsdfsim_amd.experiments inertia --scenes 8 --iters 10
+    python -m diffsdfsim_amd.experiments primitives --kind box --scenes 8 --iters 50
     python -m diffsdfsim_amd.experiments sysid --goal mass --scenes 8 --iters 20
 """
 import argparse
@@ -90,8 +94,16 @@ def trajectory_loss(traj, target, body=-1):
 def chamfer(a, b):
     """pytorch3d.loss.chamfer_distance of two point sets a [Na,3], b [Nb,3] (defaults: squared distances, mean over the points of
     each set, the two directions summed)."""
-    d = torch.cdist(a, b) ** 2
-    return d.min(dim=1).values.mean() + d.min(dim=0).values.mean()
+    # on the device, a block of rows at a time: level-set meshes have 10^4 - 10^5 vertices
+    dev = torch.device("cuda") if torch.cuda.is_available() and not a.is_cuda else a.device
+    a, b = a.to(dev), b.to(dev)
+    to_b = torch.full((b.shape[0],), float("inf"), dtype=a.dtype, device=dev)
+    to_a = a.new_zeros(())
+    for i in range(0, a.shape[0], 4096):
+        d = torch.cdist(a[i:i + 4096], b) ** 2
+        to_a = to_a + d.min(dim=1).values.sum()
+        to_b = torch.minimum(to_b, d.min(dim=0).values)
+    return to_a / a.shape[0] + to_b.mean()
 
 
 # ---- trajectory fitting: a sphere thrown at a wall (optim_sphere.py) --------------------------------------------------------
@@ -207,16 +219,41 @@ def spin_world(latents, torque_dirs, packed, scale=1.0, mass=1.0, res=128, steps
         vt = v * scale
         Is.append(mass_properties.mesh_inertia_diff(vt, f, torch.tensor(float(mass), dtype=torch.float64)).cpu())
         ms.append((vt.detach().cpu().numpy(), f.cpu().numpy()))
-    inertia = torch.stack(Is)[:, None]                                        # [B,1,3,3], graph to the latents
+    return _spin_world(torch.stack(Is), ms, scale, mass, steps, device)
+
+
+def _spin_world(inertias, ms, scale, mass, steps, device):
+    """One free-spinning body per scene with the given body-frame inertia tensors [B, 3, 3] (graph kept) and meshes."""
+    B = len(ms)
+    inertia = inertias[:, None]                                               # [B,1,3,3], graph to the shape parameters
     one = lambda a: np.tile(np.asarray(a, np.float64), (B, 1, 1))
     spec = dict(pose=one([1.0, 0, 0, 0, 0, 0, 0]), vel=one(np.zeros(6)), mass=np.full((B, 1), float(mass)),
                 inertia=inertia.detach().numpy(), restitution=np.zeros((B, 1)), fric=np.zeros((B, 1)), fext=np.zeros((B, 1, 6)),
                 shape_type=np.full((B, 1), abi.SHAPE_SPHERE, np.int32), shape_prm=one([scale, 0, 0]),      # (nothing collides: the shape is never queried)
-                mesh_id=np.arange(B, dtype=np.int32)[:, None], meshes=ms, mesh_vgrad=[np.zeros_like(m[0]) for m in ms],
+                # (a lone body per scene: the stepper never searches its mesh, so it gets one shared triangle instead of B
+                # level-set meshes of 10^5 faces whose search structures would take seconds to build; the real meshes stay on
+                # the world object for the chamfer distance)
+                mesh_id=np.zeros((B, 1), np.int32), meshes=[(0.1 * np.eye(3), np.array([[0, 1, 2]]))], mesh_vgrad=[np.zeros((3, 3))],
                 Je=np.tile(np.concatenate([np.zeros((3, 3)), np.eye(3)], 1), (B, 1, 1)), no_contact=np.zeros((1, 1), np.uint8))
     w = BatchWorld3D(spec, params=dict(inertia=inertia), max_substeps=steps + 16, device=device)
     w.meshes = ms
     return w
+
+
+PRIMITIVES = {"box": 3, "sphere": 1, "cylinder": 2}      # parameters per kind (optim_primitives.py:77-92)
+
+
+def primitive_spin_world(kind, dims, mass=1.0, steps=64, device=None):
+    """optim_primitives.py:95-115 for one scene per parameter row: an SDFBox / SDFSphere / SDFCylinder at the origin with the
+    reference's defaults there (custom_mesh = custom_inertia = False: marching-cubes mesh of the analytic SDF, inertia from that
+    mesh, differentiable w.r.t. the dimensions through the mesher), translation locked."""
+    from .physics3d import SDFBox, SDFCylinder, SDFSphere
+    make = {"box": lambda d: SDFBox([0, 0, 0], d, mass=mass, custom_mesh=False, custom_inertia=False),
+            "sphere": lambda d: SDFSphere([0, 0, 0], d[0], mass=mass, custom_mesh=False, custom_inertia=False),
+            "cylinder": lambda d: SDFCylinder([0, 0, 0], rad=d[0], height=d[1], mass=mass, custom_mesh=False, custom_inertia=False)}[kind]
+    bodies = [make(dims[s]) for s in range(dims.shape[0])]
+    ms = [(b.verts_np, np.asarray(b.faces_np)) for b in bodies]
+    return _spin_world(torch.stack([b.ang_inertia.to(torch.float64).cpu() for b in bodies]), ms, 1.0, mass, steps, device)
 
 
 def run_spin(world, torque_dirs, run_time=2.0, torque_time=0.3):
@@ -258,6 +295,40 @@ def fit_inertia_latent(target_latents, start_latents, torque_dirs, packed, run_t
             lat -= lr * lat.grad
         last = l
     return dict(latent=lat.detach().numpy().copy(), target=np.asarray(target_latents), history=hist)
+
+
+def fit_inertia_primitive(kind, target_dims, start_dims, torque_dirs, run_time=2.0, max_iter=200, lr=1e-2, conv_thresh=1e-5,
+                          min_dim=0.5, max_dim=2.0, optimizer="Adam", log=None):
+    """optim_primitives.py:160-240 for B (target, start) rows at once: Adam (or plain gradient descent) on the dimensions so
+    that the final velocity under the torque matches the target's; dimensions clamped to [min_dim, max_dim] after each update;
+    stops when no scene's loss moved by more than conv_thresh."""
+    steps = int(math.ceil(run_time / Defaults3D.DT)) + 2
+    tgt = torch.as_tensor(np.asarray(target_dims, np.float64)).reshape(-1, PRIMITIVES[kind])
+    with torch.no_grad():
+        wt = primitive_spin_world(kind, tgt, steps=steps)
+        v_target = run_spin(wt, torque_dirs, run_time).clone()
+    dims = torch.tensor(np.asarray(start_dims, np.float64).reshape(-1, PRIMITIVES[kind]), requires_grad=True)
+    opt = torch.optim.Adam([dims], lr=lr) if optimizer == "Adam" else torch.optim.SGD([dims], lr=lr)
+    hist, last = [], None
+    for e in range(max_iter):
+        opt.zero_grad()
+        w = primitive_spin_world(kind, dims, steps=steps)
+        v = run_spin(w, torque_dirs, run_time)
+        loss = ((v - v_target.to(v)) ** 2).sum(dim=1)
+        loss.sum().backward()
+        l = loss.detach().cpu().numpy()
+        d = np.array([float(chamfer(torch.as_tensor(a[0]), torch.as_tensor(b[0]))) for a, b in zip(w.meshes, wt.meshes)])
+        hist.append(dict(iter=e, loss=l.copy(), dims=dims.detach().numpy().copy(), grad=dims.grad.numpy().copy(), chamfer=d))
+        if log:
+            log("iter %3d  mean loss %.3e  mean chamfer %.3e  mean |dims - target| %.4f" %
+                (e, float(l.mean()), float(d.mean()), float((dims.detach() - tgt).abs().mean())))
+        if last is not None and np.all(np.abs(last - l) < conv_thresh):
+            break
+        opt.step()
+        with torch.no_grad():
+            dims.clamp_(min_dim, max_dim)
+        last = l
+    return dict(dims=dims.detach().numpy().copy(), target=tgt.numpy(), history=hist)
 
 
 # ---- system identification (experiments/system_identification/optim_sysid.py) --------------------------------------------
@@ -353,8 +424,9 @@ def export_trajectory(path, pose, vel, **meta):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace, system_identification/optim_sysid)")
-    ap.add_argument("what", choices=["sphere", "inertia", "sysid"])
+    ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace and optim_primitives, system_identification/optim_sysid)")
+    ap.add_argument("what", choices=["sphere", "inertia", "primitives", "sysid"])
+    ap.add_argument("--kind", default="box", choices=sorted(PRIMITIVES))
     ap.add_argument("--goal", default="mass", choices=["mass", "force", "friction"])
     ap.add_argument("--run-time", type=float, default=1.0)
     ap.add_argument("--scenes", type=int, default=64)
@@ -373,6 +445,14 @@ def main(argv=None):
         print(radius_error_table(res))
         if a.out:
             np.savez_compressed(a.out, **{k.replace(" ", "_").replace(",", ""): v["radius"] for k, v in res.items()}, target=target, start=start)
+    elif a.what == "primitives":
+        # optim_primitives.py:160-175: target and start dimensions ~ U(0.5, 2.0), a random unit torque direction per scene
+        n = PRIMITIVES[a.kind]
+        tgt, st = 0.5 + 1.5 * r.random((a.scenes, n)), 0.5 + 1.5 * r.random((a.scenes, n))
+        dirs = r.standard_normal((a.scenes, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        res = fit_inertia_primitive(a.kind, tgt, st, dirs, run_time=a.run_time if a.run_time != 1.0 else 2.0, max_iter=a.iters, log=print)
+        d0, d1 = np.abs(st - tgt).mean(), np.abs(res["dims"] - tgt).mean()
+        print("%s: mean |dims - target| %.4f -> %.4f, final mean loss %.3e, %d scenes" % (a.kind, d0, d1, float(res["history"][-1]["loss"].mean()), a.scenes))
     elif a.what == "sysid":
         # optim_sysid.py:184-220: a random latent, push, mass and friction per scene; the goal's start value is drawn anew
         from . import igr
