@@ -10,6 +10,9 @@ trajectory fitting  (experiments/trajectory_fitting/optim_sphere.py)
     chamfer(a, b)                                 symmetric mean squared nearest-neighbour distance (pytorch3d.loss.chamfer_distance, :244)
     fit_sphere_radius(...)                        the gradient-descent loop (:210-270) for B (target, start) pairs; radius_error_table()
                                                   prints min / mean / max |r - r*| like RESULTS.md:14-47
+trajectory fitting in shape space  (experiments/trajectory_fitting/optim_shapespace.py)
+    bounce_world_latent(latents, packed, ...)     the same scene with a neural-SDF body in place of the sphere (:90-124)
+    fit_trajectory_latent(...)                    the loop over the latent code
 inertia fitting  (experiments/inertia_fitting/optim_shapespace.py)
     spin_world(latents, torque_dirs, net)         one neural-SDF body per scene, translation locked (X/Y/Z constraints), torque for
                                                   t < 0.3 (:71-92); inertia from the body's level-set mesh, differentiable w.r.t. the latent
@@ -24,6 +27,7 @@ system identification  (experiments/system_identification/optim_sysid.py)
     fit_sysid(goal, ...)                          the loop of :184-300 for goal in ('mass', 'force', 'friction')
 
     python -m diffsdfsim_amd.experiments sphere --scenes 64 --iters 100
+    python -m diffsdfsim_amd.experiments shapespace --scenes 4 --iters 10
     python -m diffsdfsim_amd.experiments inertia --scenes 8 --iters 10
     python -m diffsdfsim_amd.experiments primitives --kind box --scenes 8 --iters 50
     python -m diffsdfsim_amd.experiments sysid --goal mass --scenes 8 --iters 20
@@ -205,6 +209,102 @@ def radius_error_table(results):
         err = np.abs(r["radius"] - r["target"])
         rows.append("%-22s min %.1e  mean %.4f  max %.4f   (%d scenes)" % (name, err.min(), err.mean(), err.max(), len(err)))
     return "\n".join(rows)
+
+
+# ---- trajectory fitting in shape space: a neural-SDF body thrown at a wall (trajectory_fitting/optim_shapespace.py) ----------
+def bounce_world_latent(latents, packed, use_toc_diff=True, use_friction=True, use_wall=True, use_floor=True, use_gravity=False,
+                        obj_pos=(0.0, 5.0, 0.0), obj_vel=(5.0, 0.0, 0.0), run_time=1.5, dt=Defaults3D.DT, res=128, device=None):
+    """trajectory_fitting/optim_shapespace.py:90-124 for one scene per latent code: floor 50 x 1 x 50, wall [5,5,0] 1 x 10 x 10
+    (pinned, no contact with each other), the neural-SDF body (scale 1, mass 1) at (0,5,0) thrown with (5,0,0); restitution
+    0.5, friction 0.25; no gravity by default, strict_no_penetration=False.  With `latents` a tensor that requires grad the
+    scene is differentiable w.r.t. it three ways, as the reference's is: the SDF the contacts query, the level-set mesh
+    (MeshSDF) the contact candidates come from, and the inertia integrated over that mesh."""
+    lat_t = torch.as_tensor(latents, dtype=torch.float64)
+    lat = lat_t.detach().cpu().numpy()
+    B = lat.shape[0]
+    fixed = [n for n, on in (("floor", use_floor), ("wall", use_wall)) if on]
+    nb = len(fixed) + 1
+    mu = 0.25 if use_friction else 0.0
+    spec, cache = scenes._base(B, nb), {}
+    spec["Je"] = np.zeros((B, 6 * len(fixed), 6 * nb))
+    nocon = np.zeros((nb, nb), np.uint8)
+    for k, name in enumerate(fixed):
+        dims, pos = ((50.0, 1.0, 50.0), (0.0, -0.5, 0.0)) if name == "floor" else ((1.0, 10.0, 10.0), (5.0, 5.0, 0.0))
+
+        def make(dims=dims):
+            v, f, tie = meshes.box_mesh(np.asarray(dims))
+            return v, f, 0.5 * tie
+        spec["mesh_id"][:, k] = scenes._add_mesh(spec, cache, ("box",) + tuple(dims), make)
+        spec["pose"][:, k, 4:] = pos
+        spec["shape_prm"][:, k] = dims
+        spec["inertia"][:, k] = scenes.box_inertia(1.0, np.asarray(dims))
+        spec["fric"][:, k] = mu
+        spec["restitution"][:, k] = Defaults3D.RESTITUTION
+        spec["Je"][:, 6 * k:6 * k + 6, 6 * k:6 * k + 6] = np.eye(6)
+    if len(fixed) == 2:
+        nocon[0, 1] = nocon[1, 0] = 1
+    spec["no_contact"] = nocon
+    s_ = nb - 1
+    spec["shape_aux"] = np.zeros((B, nb))
+    spec["igr_net"] = packed
+    spec["shape_type"][:, s_] = abi.SHAPE_IGR
+    spec["shape_aux"][:, s_] = 1.0
+    one = torch.tensor(1.0, dtype=torch.float64)
+    vts, Is = [torch.as_tensor(m[0], dtype=torch.float64) for m in spec["meshes"]], []
+    for s in range(B):
+        v, f = meshsdf.igr_mesh(lat_t[s], packed, res=res)
+        Is.append(mass_properties.mesh_inertia_diff(v, f, one).cpu())
+        spec["meshes"].append((v.detach().cpu().numpy(), f.cpu().numpy())); spec["mesh_vgrad"].append(np.zeros((v.shape[0], 3)))
+        spec["mesh_id"][s, s_] = len(spec["meshes"]) - 1
+        vts.append(v)
+    spec["shape_prm"][:, s_, :2] = lat
+    spec["pose"][:, s_, 4:] = obj_pos
+    spec["vel"][:, s_, 3:] = obj_vel
+    spec["inertia"][:, s_] = torch.stack(Is).detach().numpy()
+    spec["fric"][:, s_] = mu
+    spec["restitution"][:, s_] = Defaults3D.RESTITUTION
+    if use_gravity:
+        spec["fext"][:, s_, 4] = -10.0
+    params = {}
+    if lat_t.requires_grad:
+        prm = torch.tensor(spec["shape_prm"], dtype=torch.float64)
+        mine = torch.cat([lat_t.cpu(), torch.zeros(B, 1, dtype=torch.float64)], 1)[:, None]
+        inertia = torch.tensor(spec["inertia"], dtype=torch.float64)
+        dev = vts[-1].device
+        params = dict(shape_prm=torch.cat([prm[:, :s_], mine], 1), inertia=torch.cat([inertia[:, :s_], torch.stack(Is)[:, None]], 1),
+                      verts=torch.cat([v.to(dev) for v in vts]))
+    steps = int(math.ceil(run_time / dt)) + 2
+    return BatchWorld3D(spec, params=params, dt=dt, time_of_contact_diff=use_toc_diff, strict_no_penetration=False,
+                        max_substeps=8 * steps + 64, device=device, maxc=256, max_cand=8192, max_pc=128)
+
+
+def fit_trajectory_latent(target_latents, start_latents, packed, run_time=1.5, max_iter=100, lr=1e-2, conv_thresh=1e-7,
+                          detach_2nd_bounce=True, log=None, **scene):
+    """trajectory_fitting/optim_shapespace.py:260-330 for B scenes at once: gradient descent on the latent code so that the
+    thrown body's trajectory (its positions at the nearest target times, trajectory_loss) matches the target's."""
+    with torch.no_grad():
+        target = run_world_fixed_dt(bounce_world_latent(torch.as_tensor(np.asarray(target_latents, np.float64)), packed,
+                                                        run_time=run_time, **scene), run_time)
+    lat = torch.tensor(np.asarray(start_latents, np.float64), requires_grad=True)
+    hist, last = [], None
+    for e in range(max_iter):
+        if lat.grad is not None:
+            lat.grad = None
+        world = bounce_world_latent(lat, packed, run_time=run_time, **scene)
+        traj = run_world_fixed_dt(world, run_time, detach_2nd_bounce=detach_2nd_bounce)
+        loss = trajectory_loss(traj, target)
+        loss.sum().backward()
+        l = loss.detach().cpu().numpy()
+        hist.append(dict(iter=e, loss=l.copy(), latent=lat.detach().numpy().copy(), grad=lat.grad.numpy().copy()))
+        if log:
+            log("iter %3d  mean loss %.3e  mean |latent - target| %.4f  |grad| %.3e" %
+                (e, float(l.mean()), float(np.abs(lat.detach().numpy() - np.asarray(target_latents)).mean()), float(lat.grad.abs().mean())))
+        if last is not None and np.all(np.abs(last - l) < conv_thresh):
+            break
+        with torch.no_grad():
+            lat -= lr * lat.grad
+        last = l
+    return dict(latent=lat.detach().numpy().copy(), target=np.asarray(target_latents), history=hist)
 
 
 # ---- inertia fitting: a neural-SDF body spun by a torque (optim_shapespace.py) ------------------------------------------------
@@ -425,7 +525,7 @@ def export_trajectory(path, pose, vel, **meta):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description="batched experiment drivers (trajectory_fitting/optim_sphere, inertia_fitting/optim_shapespace and optim_primitives, system_identification/optim_sysid)")
-    ap.add_argument("what", choices=["sphere", "inertia", "primitives", "sysid"])
+    ap.add_argument("what", choices=["sphere", "shapespace", "inertia", "primitives", "sysid"])
     ap.add_argument("--kind", default="box", choices=sorted(PRIMITIVES))
     ap.add_argument("--goal", default="mass", choices=["mass", "force", "friction"])
     ap.add_argument("--run-time", type=float, default=1.0)
@@ -445,6 +545,12 @@ def main(argv=None):
         print(radius_error_table(res))
         if a.out:
             np.savez_compressed(a.out, **{k.replace(" ", "_").replace(",", ""): v["radius"] for k, v in res.items()}, target=target, start=start)
+    elif a.what == "shapespace":
+        from . import igr
+        packed = igr.pack_weights(*scenes.geometric_init_weights(a.seed, 0.5))
+        tgt, st = 0.1 * r.standard_normal((a.scenes, 2)), 0.1 * r.standard_normal((a.scenes, 2))
+        res = fit_trajectory_latent(tgt, st, packed, run_time=a.run_time if a.run_time != 1.0 else 1.5, max_iter=a.iters, log=print)
+        print("shapespace: mean loss %.3e -> %.3e, %d scenes" % (float(res["history"][0]["loss"].mean()), float(res["history"][-1]["loss"].mean()), a.scenes))
     elif a.what == "primitives":
         # optim_primitives.py:160-175: target and start dimensions ~ U(0.5, 2.0), a random unit torque direction per scene
         n = PRIMITIVES[a.kind]
