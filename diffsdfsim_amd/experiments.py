@@ -278,21 +278,23 @@ def bounce_world_latent(latents, packed, use_toc_diff=True, use_friction=True, u
                         max_substeps=8 * steps + 64, device=device, maxc=256, max_cand=8192, max_pc=128)
 
 
-def fit_trajectory_latent(target_latents, start_latents, packed, run_time=1.5, max_iter=100, lr=1e-2, conv_thresh=1e-7,
-                          detach_2nd_bounce=True, log=None, **scene):
-    """trajectory_fitting/optim_shapespace.py:260-330 for B scenes at once: gradient descent on the latent code so that the
-    thrown body's trajectory (its positions at the nearest target times, trajectory_loss) matches the target's."""
+def fit_trajectory_latent(target_latents, start_latents, packed, run_time=1.0, max_iter=100, lr=1e-3, conv_thresh=1e-5,
+                          latent_reg=1e-4, optimizer="Adam", detach_2nd_bounce=True, log=None, **scene):
+    """trajectory_fitting/optim_shapespace.py:232-320 for B scenes at once (its settings: Adam, lr 1e-3, run_time 1,
+    latent_reg 1e-4): the latent code is fitted so that the thrown body's trajectory (its positions at the nearest target
+    times, trajectory_loss) matches the target's; loss = trajectory_loss + latent_reg |latent|^2."""
     with torch.no_grad():
         target = run_world_fixed_dt(bounce_world_latent(torch.as_tensor(np.asarray(target_latents, np.float64)), packed,
                                                         run_time=run_time, **scene), run_time)
     lat = torch.tensor(np.asarray(start_latents, np.float64), requires_grad=True)
+    opt = torch.optim.Adam([lat], lr=lr) if optimizer == "Adam" else torch.optim.SGD([lat], lr=lr)
     hist, last = [], None
     for e in range(max_iter):
-        if lat.grad is not None:
-            lat.grad = None
+        opt.zero_grad()
         world = bounce_world_latent(lat, packed, run_time=run_time, **scene)
         traj = run_world_fixed_dt(world, run_time, detach_2nd_bounce=detach_2nd_bounce)
         loss = trajectory_loss(traj, target)
+        loss = loss + latent_reg * (lat.to(loss.device) ** 2).sum(dim=1)
         loss.sum().backward()
         l = loss.detach().cpu().numpy()
         hist.append(dict(iter=e, loss=l.copy(), latent=lat.detach().numpy().copy(), grad=lat.grad.numpy().copy()))
@@ -301,8 +303,7 @@ def fit_trajectory_latent(target_latents, start_latents, packed, run_time=1.5, m
                 (e, float(l.mean()), float(np.abs(lat.detach().numpy() - np.asarray(target_latents)).mean()), float(lat.grad.abs().mean())))
         if last is not None and np.all(np.abs(last - l) < conv_thresh):
             break
-        with torch.no_grad():
-            lat -= lr * lat.grad
+        opt.step()
         last = l
     return dict(latent=lat.detach().numpy().copy(), target=np.asarray(target_latents), history=hist)
 
@@ -549,7 +550,7 @@ def main(argv=None):
         from . import igr
         packed = igr.pack_weights(*scenes.geometric_init_weights(a.seed, 0.5))
         tgt, st = 0.1 * r.standard_normal((a.scenes, 2)), 0.1 * r.standard_normal((a.scenes, 2))
-        res = fit_trajectory_latent(tgt, st, packed, run_time=a.run_time if a.run_time != 1.0 else 1.5, max_iter=a.iters, log=print)
+        res = fit_trajectory_latent(tgt, st, packed, run_time=a.run_time, max_iter=a.iters, log=print)
         print("shapespace: mean loss %.3e -> %.3e, %d scenes" % (float(res["history"][0]["loss"].mean()), float(res["history"][-1]["loss"].mean()), a.scenes))
     elif a.what == "primitives":
         # optim_primitives.py:160-175: target and start dimensions ~ U(0.5, 2.0), a random unit torque direction per scene
