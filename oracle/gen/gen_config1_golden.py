@@ -72,5 +72,34 @@ def main():
           [tuple(c["ops"][2].shape) for c in calls][:5])
 
 
+def polygons():
+    """A second 2-D scene with polygon / polygon and circle / polygon contacts in one world (a tilted box landing on a corner
+    and tipping onto its face, a ball rolling into it, on a pinned slab): contact pairs per step, final poses and
+    d loss / d (box width, ball radius) -> tests/golden/config1_polygons.npz."""
+    wd = torch.tensor(80.0, dtype=torch.double, requires_grad=True)
+    rad = torch.tensor(25.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.2, fric_coeff=0.6)
+    box = Rect([0.3, 420, 520], torch.stack([wd, wd.new_tensor(50.0)]), restitution=0.2, fric_coeff=0.6)
+    ball = Circle([560, 500], rad, vel=[0, -150, 0], restitution=0.2, fric_coeff=0.6)
+    for b in (box, ball):
+        b.add_force(Gravity(g=100))
+    w = World([floor, box, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+    pairs, traj = [], []
+    for _ in range(60):
+        w.step()
+        row = np.full((8, 2), -1, np.int64)
+        for k, c in enumerate(w.contacts):
+            row[k] = (c[1], c[2])
+        pairs.append(row)
+        traj.append(torch.cat([b.p for b in (floor, box, ball)]).detach().numpy())
+    loss = (box.p ** 2).sum() + (ball.pos ** 2).sum()
+    gw, gr = torch.autograd.grad(loss, [wd, rad])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1_polygons.npz"), pairs=np.stack(pairs), traj_p=np.stack(traj),
+                        loss=float(loss), g_width=float(gw), g_rad=float(gr), n_substeps=np.int64(len(w.trajectory)), t_final=float(w.t))
+    print("polygon scene: %d sub-steps, loss %.6f, d/d width %.6f, d/d rad %.6f, pairs seen %s" %
+          (len(w.trajectory), float(loss), float(gw), float(gr), sorted({tuple(r) for s_ in pairs for r in s_ if r[0] >= 0})))
+
+
 if __name__ == "__main__":
     main()
+    polygons()

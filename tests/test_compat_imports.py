@@ -15,6 +15,13 @@ from sdf_physics.physics3d.forces import Gravity3D, ExternalForce3D
 from sdf_physics.physics3d.utils import get_tensor, Rx, Ry, Recorder3D, Defaults3D, load_igrnet, decode_igr
 from sdf_physics.physics3d.world import World3D, run_world
 from lcp_physics.lcp.lcp import LCPFunction
+from lcp_physics.physics.bodies import Circle, Rect, Hull
+from lcp_physics.physics.constraints import TotalConstraint
+from lcp_physics.physics.forces import Gravity
+from lcp_physics.physics.contacts import DiffContactHandler
+from lcp_physics.physics.world import World, run_world as run_world_2d
+import diffsdfsim_amd.physics2d as P2
+assert World is P2.World and Circle is P2.Circle and DiffContactHandler is P2.DiffContactHandler
 import diffsdfsim_amd.physics3d as P
 assert World3D is P.World3D and SDF3D is P.SDF3D and run_world is P.run_world
 assert Defaults3D.CUSTOM_MESH is False and Defaults3D.CUSTOM_INERTIA is False and Defaults3D.FRIC_DIRS == 8

@@ -163,3 +163,56 @@ def test_vector_jacobian_product_against_central_differences_of_the_restatement(
         assert abs(fd1 - ad[p]) < 2e-5 * max(1.0, abs(fd1)), (p, fd1, ad[p], a["kind"][:, p])
         checked += 1
     assert checked > 250
+
+
+def test_config1_end_to_end_on_the_device_library():
+    """BASELINE configs[0] without the reference: the 2-D world of diffsdfsim_amd.physics2d (contacts of all pairs from the
+    contact kernel, the LCP from the dense kernel, assembly in torch on the device), 50 steps forward + backward, against what
+    the reference's own world produced (tests/golden/config1_lcp.npz): number of LCP solves and sub-steps, final poses, loss,
+    d loss / d radius."""
+    from diffsdfsim_amd.physics2d import Circle, Gravity, Rect, TotalConstraint, World
+    g = np.load(os.path.join(GOLDEN, "config1_lcp.npz"))
+    rad = torch.tensor(20.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.5, fric_coeff=0.9)
+    ball = Circle([500, 480], rad, vel=[0, 30, 0], restitution=0.5, fric_coeff=0.9)
+    ball.add_force(Gravity(g=100))
+    w = World([floor, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+    for _ in range(50):
+        w.step()
+    loss = (ball.pos ** 2).sum()
+    loss.backward()
+    assert w.lcp_calls == int(g["n_calls"]) and len(w.trajectory) == int(g["n_substeps"])
+    assert abs(w.t - float(g["t_final"])) < 1e-12
+    final_p = torch.cat([floor.p, ball.p]).detach().cpu().numpy()
+    assert np.abs(final_p - g["final_p"]).max() < 1e-8 * np.abs(g["final_p"]).max()
+    assert abs(float(loss) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
+    assert abs(float(rad.grad) - float(g["drad"])) < 1e-6 * abs(float(g["drad"])), (float(rad.grad), float(g["drad"]))
+
+
+def test_polygon_scene_end_to_end_against_the_reference_world():
+    """Polygon against polygon (reference / incident edge and clipping: a tilted box landing on a corner and tipping onto its
+    face) and circle against polygon (a ball rolling into the box) in one 2-D world on the device library, 60 steps, against
+    the reference's own world (tests/golden/config1_polygons.npz): contact pairs of every step, poses along the way, loss and
+    d loss / d (box width, ball radius)."""
+    from diffsdfsim_amd.physics2d import Circle, Gravity, Rect, TotalConstraint, World
+    g = np.load(os.path.join(GOLDEN, "config1_polygons.npz"))
+    wd = torch.tensor(80.0, dtype=torch.double, requires_grad=True)
+    rad = torch.tensor(25.0, dtype=torch.double, requires_grad=True)
+    floor = Rect([500, 600], [1000, 50], restitution=0.2, fric_coeff=0.6)
+    box = Rect([0.3, 420, 520], torch.stack([wd, wd.new_tensor(50.0)]), restitution=0.2, fric_coeff=0.6)
+    ball = Circle([560, 500], rad, vel=[0, -150, 0], restitution=0.2, fric_coeff=0.6)
+    for b in (box, ball):
+        b.add_force(Gravity(g=100))
+    w = World([floor, box, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+    for k in range(60):
+        w.step()
+        want = [tuple(r) for r in g["pairs"][k] if r[0] >= 0]
+        assert [(c[1], c[2]) for c in w.contacts] == want, (k, want)
+        p = torch.cat([b.p for b in (floor, box, ball)]).detach().cpu().numpy()
+        assert np.abs(p - g["traj_p"][k]).max() < 1e-7 * np.abs(g["traj_p"][k]).max(), k
+    assert len(w.trajectory) == int(g["n_substeps"])
+    loss = (box.p ** 2).sum() + (ball.pos ** 2).sum()
+    gw, gr = torch.autograd.grad(loss, [wd, rad])
+    assert abs(float(loss) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
+    assert abs(float(gw) - float(g["g_width"])) < 1e-5 * abs(float(g["g_width"])), (float(gw), float(g["g_width"]))
+    assert abs(float(gr) - float(g["g_rad"])) < 1e-5 * abs(float(g["g_rad"])), (float(gr), float(g["g_rad"]))
