@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
     stamp = os.path.join(objdir, "flags.txt")
-    flagsig = " ".join(extra) + repr(sorted(PER_FILE_FLAGS.items())) + repr(_NO_LSR) + repr(sorted(_DEFAULT_LLVM.items()))
+    flagsig = " ".join(extra) + repr(sorted(PER_FILE_FLAGS.items())) + repr(_NO_LSR) + repr(sorted(_DEFAULT_LLVM.items())) + "cuid=stem"
     if not os.path.exists(stamp) or open(stamp).read() != flagsig:
         force = True
     hnew = max([os.path.getmtime(h) for h in hdrs] + [os.path.getmtime(__file__)])
@@ -68,7 +68,9 @@ def build(force=False, verbose=False):
             dep = max(dep, os.path.getmtime(os.path.join(CSRC, name[:-8] + ".hip")))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(dep, hnew):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"] + extra + \
+        # -cuid=<file stem>: the compilation-unit id is otherwise hashed from the source's absolute path; with a fixed one the
+        # library (and the hash the counter files are stamped with) does not depend on where the tree is checked out
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-cuid=dss_" + name[:-4]] + extra + \
             file_flags(name) + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
