@@ -30,8 +30,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB
 FP64_PEAK_TFLOPS = 78.6      # vector and matrix fp64 alike: 256 CU x 128 flop/clk x 2.4 GHz
 IGR_MAC_PER_POINT = 115456   # 5*128 + 6*128*128 + 123*128 + 128: one network evaluation (igr_mlp.hip)
 
-DEFAULTS = {2: dict(batch=256, steps=200), 3: dict(batch=1024, steps=200), 4: dict(batch=512, steps=100), 5: dict(batch=1024, steps=200)}
-WORKLOAD = {2: "configs[1]: %d sphere-drop scenes (floor + SDF sphere, TOC on), %d steps fwd + reverse sweep",
+DEFAULTS = {1: dict(batch=1, steps=50), 2: dict(batch=256, steps=200), 3: dict(batch=1024, steps=200), 4: dict(batch=512, steps=100), 5: dict(batch=1024, steps=200)}
+WORKLOAD = {1: "configs[0]: 2-D ball on a pinned slab (Circle + Rect, analytic contact), batch %d, %d steps fwd + backward",
+            2: "configs[1]: %d sphere-drop scenes (floor + SDF sphere, TOC on), %d steps fwd + reverse sweep",
             3: "configs[2]: floor + 7-box SDF stack with friction, %d scenes per GPU, %d steps fwd + reverse sweep",
             4: "configs[3]: demo_meshsdf scene (level-set floor, pole, neural-SDF body on the fp64 matrix cores), %d scenes per GPU, %d steps fwd + reverse sweep",
             5: "configs[4] shape: %d contact-free single-body scenes per GPU (X/Y/Z constraints, torque), %d steps fwd + reverse sweep"}
@@ -175,6 +176,47 @@ def build_engine(args, rank, dev):
     return BatchEngine(spec, maxc=8, max_cand=64, max_pc=8, max_sub=(K + Wm) + 16, backend=be)
 
 
+def bench_config1(args):
+    """BASELINE configs[0], the reference's own CPU case, on the device library (diffsdfsim_amd.physics2d): batch 1, a step is
+    a handful of tiny launches with host decisions in between, so the number says what the latency of that chain is and
+    nothing about the hardware.  W untimed runs, then one timed run of K steps forward + backward."""
+    import torch
+    from diffsdfsim_amd import _lib
+    from diffsdfsim_amd.physics2d import Circle, Gravity, Rect, TotalConstraint, World
+    _lib.lib()
+    torch.cuda.set_device(0)
+    K, Wm = args.steps, args.warmup
+
+    def run():
+        rad = torch.tensor(20.0, dtype=torch.double, requires_grad=True)
+        floor = Rect([500, 600], [1000, 50], restitution=0.5, fric_coeff=0.9)
+        ball = Circle([500, 480], rad, vel=[0, 30, 0], restitution=0.5, fric_coeff=0.9)
+        ball.add_force(Gravity(g=100))
+        w = World([floor, ball], [TotalConstraint(floor)], dt=1.0 / 30)
+        for _ in range(K):
+            w.step()
+        (ball.pos ** 2).sum().backward()
+        return w, float(rad.grad)
+    for _ in range(max(1, min(Wm, 2))):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    w, g = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "sim steps/sec (fwd+bwd), BASELINE configs[0]", "value": K / dt, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": WORKLOAD[1] % (1, K), "lcp_solves": w.lcp_calls, "substeps": len(w.trajectory), "d_loss_d_rad": g,
+                   "lib_sha256": lib_hash()},
+        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                     "note": "one scene, a few 64-lane launches per step and a host decision after each: no roofline applies; the case is "
+                             "in the suite for parity (tests/test_contacts2d_gpu.py), not for throughput"},
+        "cpu_baseline": {"value": 234.0, "unit": "steps/s", "cores": 1, "kind": "reference",
+                         "sample": "the reference itself on one core of the 8-vCPU build container (SURVEY.md section 6: 50 steps fwd+bwd of this "
+                                   "scene); not timed on this host -- the reference cannot travel"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +234,8 @@ def main():
     if args.batch is None:
         args.batch = DEFAULTS[args.config]["batch"]
 
+    if args.config == 1:
+        return bench_config1(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- N children, one rank per GPU, started BEFORE anything in
         # this process touches the GPU (no exec of an initialised process); rank 0's JSON line is the children's stdout
