@@ -88,7 +88,7 @@ class Hull(Body):
     def __init__(self, ref_point, vertices, **kw):
         v = torch.stack([_t(x) for x in vertices])
         nxt = torch.roll(v, -1, 0)
-        if len(v) < 3 or len(v) > MAXV or float(((nxt[:, 0] - v[:, 0]) * (nxt[:, 1] + v[:, 1])).sum()) >= 0:
+        if len(v) < 3 or len(v) > MAXV or float(((nxt[:, 0] - v[:, 0]) * (nxt[:, 1] + v[:, 1])).sum().detach()) >= 0:
             raise ValueError("a hull needs 3..%d vertices in clockwise order (y pointing down)" % MAXV)
         cr = nxt[:, 0] * v[:, 1] - nxt[:, 1] * v[:, 0]
         centroid = (cr[:, None] * (v + nxt)).sum(0) / (6.0 * (cr / 2).sum())

@@ -100,6 +100,38 @@ def polygons():
           (len(w.trajectory), float(loss), float(gw), float(gr), sorted({tuple(r) for s_ in pairs for r in s_ if r[0] >= 0})))
 
 
+def hulls():
+    """General convex polygons (`Hull`: centroid shift of the vertices, polygon inertia; bodies.py:196-254): a pentagon and a
+    triangle dropped on the slab next to each other, the pentagon given a spin and scaled by a differentiable factor
+    -> tests/golden/config1_hulls.npz."""
+    from lcp_physics.physics.bodies import Hull
+    sc = torch.tensor(1.0, dtype=torch.double, requires_grad=True)
+    pent = [[40.0, 0.0], [12.0, 38.0], [-32.0, 24.0], [-32.0, -24.0], [12.0, -38.0]]
+    tri = [[30.0, 20.0], [-30.0, 20.0], [0.0, -35.0]]
+    floor = Rect([500, 600], [1000, 50], restitution=0.3, fric_coeff=0.5)
+    a = Hull([430, 500], [sc * torch.tensor(v, dtype=torch.double) for v in pent], vel=[1.5, 20, 0], restitution=0.3, fric_coeff=0.5)
+    b = Hull([520, 520], [torch.tensor(v, dtype=torch.double) for v in tri], vel=[0, -30, 0], restitution=0.3, fric_coeff=0.5)
+    for x in (a, b):
+        x.add_force(Gravity(g=100))
+    w = World([floor, a, b], [TotalConstraint(floor)], dt=1.0 / 30)
+    pairs, traj = [], []
+    for _ in range(50):
+        w.step()
+        row = np.full((8, 2), -1, np.int64)
+        for k, c in enumerate(w.contacts):
+            row[k] = (c[1], c[2])
+        pairs.append(row)
+        traj.append(torch.cat([x.p for x in (floor, a, b)]).detach().numpy())
+    loss = (a.p ** 2).sum() + (b.p ** 2).sum()
+    gs, = torch.autograd.grad(loss, [sc])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1_hulls.npz"), pairs=np.stack(pairs), traj_p=np.stack(traj),
+                        loss=float(loss), g_scale=float(gs), n_substeps=np.int64(len(w.trajectory)),
+                        inertia=np.array([float(a.ang_inertia), float(b.ang_inertia)]))
+    print("hull scene: %d sub-steps, loss %.6f, d/d scale %.6f, inertias %.4f %.4f, max contacts %d" %
+          (len(w.trajectory), float(loss), float(gs), float(a.ang_inertia), float(b.ang_inertia), max((r[:, 0] >= 0).sum() for r in pairs)))
+
+
 if __name__ == "__main__":
     main()
     polygons()
+    hulls()

@@ -216,3 +216,32 @@ def test_polygon_scene_end_to_end_against_the_reference_world():
     assert abs(float(loss) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
     assert abs(float(gw) - float(g["g_width"])) < 1e-5 * abs(float(g["g_width"])), (float(gw), float(g["g_width"]))
     assert abs(float(gr) - float(g["g_rad"])) < 1e-5 * abs(float(g["g_rad"])), (float(gr), float(g["g_rad"]))
+
+
+def test_general_hulls_end_to_end_against_the_reference_world():
+    """`Hull` bodies that are not rectangles (centroid shift and polygon inertia of bodies.py:196-254): a spinning pentagon,
+    scaled by a differentiable factor, and a triangle on the slab, 50 steps, against the reference's world
+    (tests/golden/config1_hulls.npz): inertias, contact pairs of every step, poses, loss and d loss / d scale."""
+    from diffsdfsim_amd.physics2d import Gravity, Hull, Rect, TotalConstraint, World
+    g = np.load(os.path.join(GOLDEN, "config1_hulls.npz"))
+    sc = torch.tensor(1.0, dtype=torch.double, requires_grad=True)
+    pent = [[40.0, 0.0], [12.0, 38.0], [-32.0, 24.0], [-32.0, -24.0], [12.0, -38.0]]
+    tri = [[30.0, 20.0], [-30.0, 20.0], [0.0, -35.0]]
+    floor = Rect([500, 600], [1000, 50], restitution=0.3, fric_coeff=0.5)
+    a = Hull([430, 500], [sc * torch.tensor(v, dtype=torch.double) for v in pent], vel=[1.5, 20, 0], restitution=0.3, fric_coeff=0.5)
+    b = Hull([520, 520], [torch.tensor(v, dtype=torch.double) for v in tri], vel=[0, -30, 0], restitution=0.3, fric_coeff=0.5)
+    assert np.abs(np.array([float(a.ang_inertia), float(b.ang_inertia)]) - g["inertia"]).max() < 1e-9
+    for x in (a, b):
+        x.add_force(Gravity(g=100))
+    w = World([floor, a, b], [TotalConstraint(floor)], dt=1.0 / 30)
+    for k in range(50):
+        w.step()
+        want = [tuple(r) for r in g["pairs"][k] if r[0] >= 0]
+        assert [(c[1], c[2]) for c in w.contacts] == want, (k, want)
+        p = torch.cat([x.p for x in (floor, a, b)]).detach().cpu().numpy()
+        assert np.abs(p - g["traj_p"][k]).max() < 1e-7 * np.abs(g["traj_p"][k]).max(), k
+    assert len(w.trajectory) == int(g["n_substeps"])
+    loss = (a.p ** 2).sum() + (b.p ** 2).sum()
+    gs, = torch.autograd.grad(loss, [sc])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
+    assert abs(float(gs) - float(g["g_scale"])) < 1e-5 * abs(float(g["g_scale"])), (float(gs), float(g["g_scale"]))
