@@ -1,5 +1,6 @@
 """The reference's 2-D world (BASELINE configs[0]: `lcp_physics.physics` -- Circle / Rect / Hull bodies, TotalConstraint, Gravity,
-`World.step`) on the device library: contacts of ALL body pairs of a step from one `dss_contacts2d_forward` launch, the mixed
+`World.step`) on the device library: contacts of the body pairs of a step from `dss_contacts2d_forward` (one launch for all pairs
+unless a polygon appears in several, see `find_contacts`), the mixed
 LCP of `PdipmEngine.solve_dynamics` from `dss_lcp_dense_forward` / `_backward` (diffsdfsim_amd.lcp.LCPFunction), state and
 Jacobian assembly as torch tensors on the device, gradients by autograd through those three.
 
@@ -175,17 +176,30 @@ class World:
 
     # -- contacts: every pair in one launch ------------------------------------------------------------------------------------
     def find_contacts(self):
+        """Contacts of all pairs, in pair order.  Pairs go to the kernel in one launch as long as no polygon appears twice: a
+        polygon's `last_sat_idx` is state that the reference carries from one pair to the next (contacts.py:124-131, 153-158),
+        so a pair that meets a polygon again starts a new launch with the index the earlier pair left."""
         self.contacts = []
-        if not self.pairs:
-            return
+        group, seen = [], set()
+        for pr in self.pairs:
+            hulls = {i for i in pr if self.bodies[i].kind == 1}
+            if hulls & seen:
+                self._detect(group)
+                group, seen = [], set()
+            group.append(pr)
+            seen |= hulls
+        if group:
+            self._detect(group)
+
+    def _detect(self, pairs):
         dev = self._M.device
-        P = len(self.pairs)
-        zero2, zero = self._M.new_zeros(2), self._M.new_zeros(())
+        P = len(pairs)
+        zero = self._M.new_zeros(())
         padv = self._M.new_zeros(MAXV, 2)
         rows = {k: ([], []) for k in ("pos", "rad", "verts")}
         meta = torch.zeros(3, 2, P, dtype=torch.int32)        # kind, nv, sat
         vcache = {}
-        for q, pr in enumerate(self.pairs):
+        for q, pr in enumerate(pairs):
             for s, i in enumerate(pr):
                 b = self.bodies[i]
                 rows["pos"][s].append(b.pos)
@@ -204,10 +218,7 @@ class World:
         out, count, sat = contacts2d(st("pos"), st("rad"), st("verts"), meta[0].contiguous(), meta[1].contiguous(),
                                      meta[2].contiguous(), self.eps)
         count, sat = count.cpu(), sat.cpu()
-        for q, (i, j) in enumerate(self.pairs):
-            # (the reference visits the pairs one after the other and a polygon's `last_sat_idx` carries over from one pair to
-            # the next within a detection; here all pairs start from the index the body had before the detection -- the same
-            # contacts, since the index only chooses where a loop over all edges starts, unless two edges tie to the last bit)
+        for q, (i, j) in enumerate(pairs):
             for s, k in enumerate((i, j)):
                 if self.bodies[k].kind == 1:
                     self.bodies[k].last_sat_idx = int(sat[s, q])
