@@ -174,7 +174,7 @@ class World:
     def get_p(self):
         return torch.cat([b.p for b in self.bodies])
 
-    # -- contacts: every pair in one launch ------------------------------------------------------------------------------------
+    # -- contacts ----------------------------------------------------------------------------------------------------------
     def find_contacts(self):
         """Contacts of all pairs, in pair order.  Pairs go to the kernel in one launch as long as no polygon appears twice: a
         polygon's `last_sat_idx` is state that the reference carries from one pair to the next (contacts.py:124-131, 153-158),
