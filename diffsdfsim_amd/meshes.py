@@ -23,8 +23,9 @@ def _grid_faces(inds):
     return np.concatenate([a, b])
 
 
-def box_mesh(dims, max_tri_length=0.1):
+def box_mesh(dims, max_tri_length=0.1, grid_axes=None):
     """Six regular grids, one per face, vertices duplicated along box edges.
+    ``grid_axes``: the three grid axes (w, h, d) to use instead of this module's linspace (parity tests pass the reference's).
 
     Follows the layout of `bodies.py:799-854` (front/back, left/right, top/bottom blocks,
     grid pitch <= ``max_tri_length``) so that face ids are comparable with the reference.
@@ -39,7 +40,8 @@ def box_mesh(dims, max_tri_length=0.1):
         # last bit depends on the host's SIMD width, so interior coordinates agree with it
         # to 1 ulp, not bit for bit (parity tests feed the reference's own mesh instead).
         n = int(nv[k])
-        lin = _linspace(-hd[k], hd[k], n)
+        lin = _linspace(-hd[k], hd[k], n) if grid_axes is None else np.array(grid_axes[k], np.float64)
+        assert len(lin) == n
         lin[0] = -hd[k]
         lin[-1] = hd[k]
         axes.append(lin)

@@ -1,0 +1,110 @@
+"""Goldens for the BENCHMARK'S OWN scenes (TEST INFRA, build container only):  python -m oracle.gen.gen_bench_golden
+
+bench.py steps `diffsdfsim_amd.scenes.box_stack(1024, seed=1000 + rank)` (configs[2], the headline config) and
+`sphere_drop(256, seed=1000 + rank)` (configs[1]).  This script rebuilds scenes 0..N-1 of those very batches with the
+REFERENCE's classes (SDFBox / SDFSphere with custom_mesh / custom_inertia, TotalConstraint3D, Gravity3D), steps them with the
+reference's `World3D.step(fixed_dt=True)` (lcp_physics/physics/world.py:119-139, 241-379) and records what
+gen_rollout_golden.py records for its scenes: every accepted sub-step (t, poses, velocities, ordered contact pairs, contact
+geometry, the reference's own `stable_mask` per contact), d sum|pos_T|^2 / d (dims | radius) from torch.autograd, and a
+second, nudged run (B) of the gradients.
+
+The floor's mesh is NOT stored (20 x 1 x 20: 176 000 faces), its three grid axes are (`floor_axes_*`): the generator asserts that
+`diffsdfsim_amd.meshes.box_mesh(dims, grid_axes=...)` rebuilds the reference's `_custom_create_mesh` output bit for bit.  (Without the
+axes the two differ in the last bit of interior grid coordinates: torch.linspace vs numpy.)
+
+Output: tests/golden/bench_stack_s<k>.npz (k = 0..7, >= 10 outer steps) and tests/golden/bench_sphere_s<k>.npz (k = 0..3,
+200 outer steps with time-of-contact differentiation on).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+from oracle.gen import contact_record  # noqa: E402
+
+contact_record.install()
+from oracle.gen import gen_rollout_golden as G  # noqa: E402
+from sdf_physics.physics3d.bodies import SDFBox, SDFSphere  # noqa: E402
+from sdf_physics.physics3d.constraints import TotalConstraint3D  # noqa: E402
+from sdf_physics.physics3d.forces import Gravity3D  # noqa: E402
+
+from diffsdfsim_amd import scenes as build_scenes  # noqa: E402   (numpy only: the scene RECIPE bench.py uses)
+from diffsdfsim_amd import meshes as build_meshes  # noqa: E402
+from diffsdfsim_amd import world_abi as abi  # noqa: E402
+
+BENCH_SEED = 1000      # bench.py: seed = 1000 + rank
+
+
+def box_axes(body):
+    """The three grid axes (w, h, d) of a reference SDFBox's custom mesh (bodies.py:799-813), read back from its vertices."""
+    v = body.verts.detach().numpy()
+    nv = (np.ceil(body.dims.detach().numpy() / 0.1)).astype(int) + 1
+    nf = nv[0] * nv[1]
+    fb = v[:nf].reshape(nv[0], nv[1], 3)
+    lr = v[2 * nf:2 * nf + nv[1] * nv[2]].reshape(nv[1], nv[2], 3)
+    return fb[:, 0, 0].copy(), fb[0, :, 1].copy(), lr[0, :, 2].copy()
+
+
+def floor_axes(bodies):
+    """extra fixture entries: the floor's 176 000-face mesh is not stored, its grid axes are"""
+    w, h, d = box_axes(bodies[0])
+    return dict(floor_axes_w=w, floor_axes_h=h, floor_axes_d=d)
+
+
+def reference_bodies(spec, s, requires_grad=True):
+    """Scene `s` of a BatchEngine spec as the reference's bodies.  Body 0 is the pinned floor (scenes.py:_floor)."""
+    T = lambda a: torch.tensor(np.asarray(a, np.float64), dtype=torch.double)
+    nb = spec["pose"].shape[1]
+    bodies, params = [], []
+    for b in range(nb):
+        kw = dict(vel=T(spec["vel"][s, b]), mass=float(spec["mass"][s, b]), restitution=float(spec["restitution"][s, b]),
+                  fric_coeff=float(spec["fric"][s, b]), custom_mesh=True, custom_inertia=True)
+        pose = T(spec["pose"][s, b])
+        if spec["shape_type"][s, b] == abi.SHAPE_BOX:
+            prm = T(spec["shape_prm"][s, b])
+            if requires_grad and b > 0:
+                prm.requires_grad_(); params.append(prm)
+            body = SDFBox(pose, prm, **kw)
+        else:
+            prm = T(spec["shape_prm"][s, b, 0])
+            if requires_grad and b > 0:
+                prm.requires_grad_(); params.append(prm)
+            body = SDFSphere(pose, prm, **kw)
+        g = -float(spec["fext"][s, b, 4]) / float(spec["mass"][s, b])
+        if g != 0.0:
+            body.add_force(Gravity3D(g=g))
+        # the build's mesh for this body is the reference's up to the last bit of the interior grid coordinates (torch.linspace
+        # vs diffsdfsim_amd.meshes._linspace); with the reference's own grid axes it must be the reference's bit for bit
+        bv, bf = spec["meshes"][int(spec["mesh_id"][s, b])]
+        assert np.abs(body.verts.detach().numpy() - np.asarray(bv)).max() < 1e-14, ("mesh vertices differ", s, b)
+        assert np.array_equal(body.faces.numpy(), np.asarray(bf)), ("mesh faces differ", s, b)
+        if spec["shape_type"][s, b] == abi.SHAPE_BOX:
+            ev, ef, _ = build_meshes.box_mesh(spec["shape_prm"][s, b], grid_axes=box_axes(body))
+            assert np.array_equal(ev, body.verts.detach().numpy()) and np.array_equal(ef, body.faces.numpy())
+        assert np.allclose(body.ang_inertia.detach().numpy(), spec["inertia"][s, b], rtol=1e-15, atol=0), ("inertia differs", s, b)
+        bodies.append(body)
+    return bodies, [TotalConstraint3D(bodies[0])], params
+
+
+def main():
+    which = sys.argv[1:] or ["stack", "sphere"]
+    if "stack" in which:
+        spec = build_scenes.box_stack(8, seed=BENCH_SEED)      # scenes 0..7 of box_stack(1024, seed=1000): same generator stream
+        full = build_scenes.box_stack(16, seed=BENCH_SEED)
+        assert np.array_equal(full["pose"][:8], spec["pose"]), "scene k must not depend on the batch size"
+        for s in range(8):
+            G.run("bench_stack_s%d" % s, lambda s=s: reference_bodies(spec, s), nsteps=10, store_mesh=False, extra=floor_axes)
+    if "sphere" in which:
+        spec = build_scenes.sphere_drop(4, seed=BENCH_SEED)
+        for s in range(4):
+            G.run("bench_sphere_s%d" % s, lambda s=s: reference_bodies(spec, s), nsteps=200, store_mesh=False, extra=floor_axes)
+
+
+if __name__ == "__main__":
+    main()

@@ -100,9 +100,10 @@ def branch_b_grads(make, nsteps, toc, jitter=1e-13, **world_kw):
     return grads, stable_arrays(w.trajectory)[0], init_stable
 
 
-def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, **world_kw):
+def run(name, make, nsteps, toc=True, fixed=(0,), store_mesh=True, extra=None, **world_kw):
     bodies, joints, params = make()
     d = describe(bodies, store_mesh=store_mesh)
+    d.update(extra(bodies) if extra else {})
     w = World3D(bodies, joints, time_of_contact_diff=toc, **world_kw)
     d["dt"], d["eps"], d["tol"], d["fric_dirs"], d["toc_diff"] = w.dt, w.eps, w.tol, w.fric_dirs, int(toc)
     d["fixed"] = np.array(fixed, np.int32)
