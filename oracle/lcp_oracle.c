@@ -29,30 +29,60 @@
 
 /* ---- dense helpers ------------------------------------------------------------------ */
 
-/* In-place LU with partial pivoting (LAPACK getrf convention: piv[k] = row swapped with k). */
+/* Hot loops are compiled for several x86 vector widths and picked at load time (the library is built once and travels to
+ * another host).  No FMA contraction anywhere (-ffp-contract=off), so every clone produces the same bits. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define SO_CLONES __attribute__((target_clones("default", "avx2", "avx512f")))
+#else
+#define SO_CLONES
+#endif
+
+/* row[j] -= sum over the kb factor rows, one at a time in ascending order (the order of the unblocked elimination) */
+SO_CLONES static void lu_row_update(int kb, int len, const double *l, double *row, const double *u, int ldu)
+{
+    for (int k = 0; k < kb; ++k) {
+        const double lk = l[k];
+        const double *uk = u + (size_t)k * ldu;
+        if (lk != 0.0)
+            for (int j = 0; j < len; ++j) row[j] -= lk * uk[j];
+    }
+}
+
+/* In-place LU with partial pivoting (LAPACK getrf convention: piv[k] = row swapped with k).  Blocked for the cache (the
+ * reference's LAPACK is): a panel of NB columns is eliminated, then every trailing row receives the panel's NB updates in one
+ * pass.  Each element still sees the same subtractions in the same order as in the textbook elimination -- bit-identical. */
 static int lu_factor(int n, double *a, int *piv)
 {
+    enum { NB = 32 };
     int info = 0;
-    for (int k = 0; k < n; ++k) {
-        int p = k;
-        double best = fabs(a[k * n + k]);
-        for (int i = k + 1; i < n; ++i) {
-            double v = fabs(a[i * n + k]);
-            if (v > best) { best = v; p = i; }
-        }
-        piv[k] = p;
-        if (best == 0.0) { info = k + 1; continue; }
-        if (p != k)
-            for (int j = 0; j < n; ++j) { double t = a[k * n + j]; a[k * n + j] = a[p * n + j]; a[p * n + j] = t; }
-        double inv = 1.0 / a[k * n + k];
-        for (int i = k + 1; i < n; ++i) {
-            double l = a[i * n + k] * inv;
-            a[i * n + k] = l;
-            if (l != 0.0) {
-                double *ri = a + i * n, *rk = a + k * n;
-                for (int j = k + 1; j < n; ++j) ri[j] -= l * rk[j];
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = n - k0 < NB ? n - k0 : NB, k1 = k0 + kb;
+        for (int k = k0; k < k1; ++k) {
+            int p = k;
+            double best = fabs(a[k * n + k]);
+            for (int i = k + 1; i < n; ++i) {
+                double v = fabs(a[i * n + k]);
+                if (v > best) { best = v; p = i; }
+            }
+            piv[k] = p;
+            if (best == 0.0) { info = k + 1; continue; }
+            if (p != k)
+                for (int j = 0; j < n; ++j) { double t = a[k * n + j]; a[k * n + j] = a[p * n + j]; a[p * n + j] = t; }
+            double inv = 1.0 / a[k * n + k];
+            for (int i = k + 1; i < n; ++i) {
+                double l = a[i * n + k] * inv;
+                a[i * n + k] = l;
+                if (l != 0.0) {
+                    double *ri = a + i * n, *rk = a + k * n;
+                    for (int j = k + 1; j < k1; ++j) ri[j] -= l * rk[j];      /* inside the panel only */
+                }
             }
         }
+        if (k1 == n) break;
+        /* the panel's own rows, right of the panel: row i takes the updates of the panel rows above it */
+        for (int i = k0 + 1; i < k1; ++i) lu_row_update(i - k0, n - k1, a + (size_t)i * n + k0, a + (size_t)i * n + k1, a + (size_t)k0 * n + k1, n);
+        /* trailing rows */
+        for (int i = k1; i < n; ++i) lu_row_update(kb, n - k1, a + (size_t)i * n + k0, a + (size_t)i * n + k1, a + (size_t)k0 * n + k1, n);
     }
     return info;
 }
@@ -149,12 +179,15 @@ static int pre_factor_kkt(kkt_t *k, const double *Q, const double *G, const doub
     double *invQ_GT = malloc(sizeof(double) * (nz * nineq + 1));
     for (int i = 0; i < nineq; ++i) for (int j = 0; j < nz; ++j) invQ_GT[j * nineq + i] = G[i * nz + j];
     lu_solve(nz, k->Q_LU, k->Q_piv, invQ_GT, nineq);
-    for (int i = 0; i < nineq; ++i)
-        for (int j = 0; j < nineq; ++j) {
-            double s = 0;
-            for (int l = 0; l < nz; ++l) s += G[i * nz + l] * invQ_GT[l * nineq + j];
-            k->R[i * nineq + j] = s + F[i * nineq + j];
+    for (int i = 0; i < nineq; ++i) {      /* (sum over l in ascending order, then + F: the order of the plain triple loop) */
+        double *Ri = k->R + (size_t)i * nineq;
+        for (int j = 0; j < nineq; ++j) Ri[j] = 0.0;
+        for (int l = 0; l < nz; ++l) {
+            const double g = G[i * nz + l], *X = invQ_GT + (size_t)l * nineq;
+            for (int j = 0; j < nineq; ++j) Ri[j] += g * X[j];
         }
+        for (int j = 0; j < nineq; ++j) Ri[j] += F[(size_t)i * nineq + j];
+    }
     free(invQ_GT);
     for (int i = 0; i < ns; ++i) k->S_piv[i] = i;
 

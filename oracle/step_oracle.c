@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 int lcp_oracle_forward1(const double *Q, const double *p, const double *G, const double *h, const double *A, const double *b,
                         const double *F, int nz, int nineq, int neq, double eps, int not_improved_lim, int max_iter,
@@ -70,6 +71,7 @@ typedef struct {
     /* trajectory: one record per accepted sub-step (world.py:373-377) */
     int nsub, sub_cap; double *tr_t, *tr_p, *tr_v; int *tr_nc; clist_t *tr_c;
     long n_attempts, n_lcp, n_lcp_rows, n_fw_cand;
+    double t_solve, t_detect;          /* seconds in solve_dynamics / find_contacts */
     hull_cb_t hull_cb;
     int err;
 } world_t;
@@ -535,8 +537,11 @@ static int any_vertex_in_cube(const body_t *a, const body_t *b)
     }
     return 0;
 }
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 static void find_contacts(world_t *W)
 {
+    const double t0 = now_s();
     W->contacts.n = 0;
     for (int i = 0; i < W->nb; ++i)
         for (int j = i + 1; j < W->nb; ++j) {
@@ -544,6 +549,7 @@ static void find_contacts(world_t *W)
             if (!(any_vertex_in_cube(&W->b[i], &W->b[j]) && any_vertex_in_cube(&W->b[j], &W->b[i]))) continue;
             if (search_contacts(W, i, j)) search_contacts(W, j, i);
         }
+    W->t_detect += now_s() - t0;
 }
 
 /* ---- dynamics ---------------------------------------------------------------------------------------------------------- */
@@ -699,7 +705,7 @@ static int step_dt(world_t *W, double dt)
         double dt_ = dt;
         if (W->toc_diff && W->have_toc) { double dtj = W->last_dt + dt_; dt_ = -W->last_dt + dtj; }
         W->n_attempts++;
-        rc = solve_dynamics(W, dt_, nv);
+        { const double t0 = now_s(); rc = solve_dynamics(W, dt_, nv); W->t_solve += now_s() - t0; }
         if (rc) break;
         for (int i = 0; i < nb; ++i) memcpy(W->b[i].v, nv + 6 * i, 6 * sizeof(double));
         for (int i = 0; i < nb; ++i) move_body(&W->b[i], dt_);
@@ -817,6 +823,7 @@ static void export_contacts(const clist_t *L, int *body, double *geom, int *stab
         if (lap) { lap[2 * c] = ct->lap[0]; lap[2 * c + 1] = ct->lap[1]; }
     }
 }
+void so_world_timers(void *h, double *out) { world_t *W = h; out[0] = W->t_solve; out[1] = W->t_detect; }
 int so_world_ncontacts(void *h) { return ((world_t *)h)->contacts.n; }
 void so_world_contacts(void *h, int *body, double *geom, int *stable, double *lap) { export_contacts(&((world_t *)h)->contacts, body, geom, stable, lap); }
 /* trajectory record k (world.py:373-377): the time BEFORE the sub-step, the state and contacts AFTER it */

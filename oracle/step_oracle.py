@@ -121,6 +121,12 @@ class World:
         lib().so_world_counters(self.h, _p(out))
         return dict(attempts=int(out[0]), lcp_solves=int(out[1]), lcp_rows=int(out[2]), fw_candidates=int(out[3]))
 
+    def timers(self):
+        """seconds spent in solve_dynamics (assembly + LCP [+ its backward]) and in find_contacts so far"""
+        out = np.zeros(2)
+        lib().so_world_timers(self.h, _p(out))
+        return dict(solve=float(out[0]), detect=float(out[1]))
+
     def state(self):
         pose, vel = np.zeros((self.nb, 7)), np.zeros((self.nb, 6))
         lib().so_world_state(self.h, _p(pose), _p(vel))

@@ -1,0 +1,170 @@
+"""GPU: the BENCHMARK'S OWN WORKLOAD against the reference and against the independent CPU oracle.
+
+(1) Scenes 0..7 of `scenes.box_stack(1024, seed=1000)` and scenes 0..3 of `scenes.sphere_drop(256, seed=1000)` -- exactly the
+    scenes bench.py steps on rank 0 -- were stepped by the REFERENCE (oracle/gen/gen_bench_golden.py -> tests/golden/bench_*.npz).
+    Here they are stepped TOGETHER as different scenes of the full-size batch (B = 1024 / 256; the other scenes are the rest of
+    the benchmark's batch) and held to north_star: contact-pair lists exact in every accepted sub-step, poses / velocities 1e-5
+    relative (held far tighter), and -- with the reference's recorded normal choices imposed on the tape (bit 30 of the face
+    word, rollout_helpers.force_reference_branches) -- gradients within 1e-5 of the reference's autograd.
+(2) 64 FRESH config-3 scenes (another seed) against oracle/step_oracle.c with scipy's Qhull behind its hull callback: contact
+    sets exact per sub-step, trajectories to 1e-7.
+"""
+import numpy as np
+import pytest
+
+import rollout_helpers as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack_engine(B, nref, **kw):
+    from diffsdfsim_amd.engine import BatchEngine
+    spec, gs = R.bench_spec("stack", B, nref)
+    return gs, BatchEngine(spec, maxc=128, max_cand=1024, max_pc=32, **kw)
+
+
+def _check_tape_against_golden(E, g, s, ptol, vtol, flicker=()):
+    """every accepted sub-step of scene s: time step count, start poses (= the reference's previous end poses), ordered
+    contact-pair list and contact count"""
+    k = len(g["traj_t"]) - 1
+    assert int(E.get("nsub")[s]) == len(g["traj_t"]), (s, int(E.get("nsub")[s]), len(g["traj_t"]))
+    tp, tv, tnc, tb = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_nc"), E.get("tp_body")
+    for j in range(1, k + 1):
+        assert np.abs(tp[j, s] - g["traj_p"][j - 1]).max() < ptol, (s, j, np.abs(tp[j, s] - g["traj_p"][j - 1]).max())
+        assert np.abs(tv[j, s] - g["traj_v"][j - 1]).max() < vtol, (s, j, np.abs(tv[j, s] - g["traj_v"][j - 1]).max())
+        n, nr = int(tnc[j, s]), int(g["traj_nc"][j - 1])
+        mine = [tuple(r) for r in tb[j, s][:, :n].T]; ref = [tuple(r) for r in g["traj_body"][j - 1][:nr]]
+        if flicker:
+            dd = lambda L: [p for i, p in enumerate(L) if i == 0 or p != L[i - 1]]
+            assert dd(mine) == dd(ref) and abs(n - nr) <= 1, (s, j)
+        else:
+            assert mine == ref, (s, j, n, nr)
+    assert np.abs(E.get("pose")[s] - g["traj_p"][k]).max() < ptol and np.abs(E.get("vel")[s] - g["traj_v"][k]).max() < vtol
+
+
+def test_benchmark_stack_scenes_in_the_full_batch_follow_the_reference():
+    """configs[2]: B = 1024, ten steps; scenes 0..7 against the reference, all 1024 for capacity and finiteness."""
+    gs, E = _stack_engine(1024, 8, max_sub=16)
+    for s, g in enumerate(gs):
+        R.check_contacts(E, s, g["init_body"], g["init_geom"], len(g["init_body"]))
+    for _ in range(10):
+        E.step()
+    assert int(E.get("overflow").max()) == 0 and np.isfinite(E.get("pose")).all()
+    for s, g in enumerate(gs):
+        # scene 4, boxes 4 -> 5: a candidate on the threshold of the contact band comes and goes from step to step in the reference's
+        # own run (tests/test_oracle_step.py has the details); the pair's count may differ by one, nothing else
+        _check_tape_against_golden(E, g, s, 1e-7, 1e-5, flicker=(s == 4))
+        if s != 4:
+            k = len(g["traj_t"]) - 1
+            R.check_contacts(E, s, g["traj_body"][k], g["traj_geom"][k], int(g["traj_nc"][k]), tol=1e-5, coin_tol=1.1e-2)
+
+
+def test_benchmark_stack_scenes_with_the_references_coin_flips_imposed():
+    """Scenes 0..7 of the benchmark batch, ten steps, taking the reference's side of every `stable_mask` coin flip while stepping
+    (rollout_helpers.impose_reference_normals: flag and normal of the contacts between two outer steps): the trajectory then
+    follows the reference's to 1e-9 (poses) / 1e-8 (velocities) at every sub-step, and d sum|pos_T|^2 / d dims equals the
+    reference's autograd to 1e-5 of the scene's largest gradient component (the stack is at rest: gradients are 1e-5 .. 1e-10
+    of the loss; a scene whose reference gradient is below 1e-7 everywhere is held to an absolute 1e-12)."""
+    gs, E = _stack_engine(64, 8, max_sub=16)
+    live = [s for s in range(8) if s != 4]       # scene 4: flickering contact count, no one-to-one map onto the reference's contacts
+    changed = {s: [R.impose_reference_normals(E, gs[s], s)] for s in live}
+    for _ in range(10):
+        E.step()
+        for s in live:
+            changed[s].append(R.impose_reference_normals(E, gs[s], s))
+    print("normal choices changed per step:", changed)
+    for s in live:
+        _check_tape_against_golden(E, gs[s], s, 1e-9, 1e-8)
+        assert R.force_reference_branches(E, gs[s], s)[1] == 0        # the tape already carries the reference's decisions
+    R.sweep(E)
+    for s in live:
+        g = gs[s]
+        got = np.concatenate(R.param_grads(E, g, s)); want = np.concatenate([g["grad_%d" % i] for i in range(7)])
+        scale = np.abs(want).max()
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() < max(1e-5 * scale, 1e-12), (s, np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("name,nsteps", [("rollout_stack1", 4), ("rollout_stack2", 3), ("rollout_stack7", 3)])
+def test_gradients_at_north_star_tolerance_with_the_references_coin_flips_imposed(name, nsteps):
+    """The scenes whose own coin flips reproduce neither recorded run of the reference (round 2 accepted 3 x the spread between
+    the reference's two runs there).  Taking run A's side of every flip while stepping: trajectory 1e-9, gradient 1e-5 --
+    north_star's tolerance, no fallback.  (The voxel-grid body's golden has a coin-flip contact that changes the contact COUNT
+    of a sub-step inside an outer step, where nothing can be imposed from outside; it keeps its own test.)  (Imposing the decisions on the reverse sweep alone is not enough: the two candidate
+    normals differ by the tilt between the faces, which the next LCP feels; that left 3e-5 .. 5e-5.)"""
+    from diffsdfsim_amd.engine import BatchEngine
+    g = R.load_rollout(name)
+    E = BatchEngine(R.spec_from_golden(g, 2), **R.engine_kwargs(g, max_sub=96, maxc=128))
+    single = len(g["traj_t"]) == nsteps         # one sub-step per outer step: the contacts between steps are the tape's
+    for s in (0, 1):
+        R.impose_reference_normals(E, g, s)
+    for _ in range(nsteps):
+        E.step()
+        if single:
+            for s in (0, 1):
+                R.impose_reference_normals(E, g, s)
+    k = len(g["traj_t"]) - 1
+    if single:
+        assert np.abs(E.get("pose")[0] - g["traj_p"][k]).max() < 1e-9 and np.abs(E.get("vel")[0] - g["traj_v"][k]).max() < 1e-8
+    for s in (0, 1):
+        print(name, "contacts matched / decisions overwritten on the tape", R.force_reference_branches(E, g, s))
+    R.sweep(E)
+    for s in (0, 1):
+        assert R.grad_error(E, g, s) < 1e-5, (name, s, R.grad_error(E, g, s))
+
+
+def test_benchmark_sphere_scenes_in_the_full_batch_follow_the_reference():
+    """configs[1]: B = 256 sphere drops, the full 200 steps with time-of-contact differentiation; scenes 0..3 against the
+    reference's recording of those very scenes (every accepted sub-step: ~490 of them, dt halving, TOC events), then the
+    reverse sweep: d sum|pos_T|^2 / d radius to 1e-5."""
+    from diffsdfsim_amd.engine import BatchEngine
+    spec, gs = R.bench_spec("sphere", 256, 4)
+    E = BatchEngine(spec, maxc=64, max_sub=640)
+    for _ in range(200):
+        E.step()
+    assert int(E.get("overflow").max()) == 0
+    for s, g in enumerate(gs):
+        _check_tape_against_golden(E, g, s, 1e-7, 1e-6)
+    for s, g in enumerate(gs):
+        R.force_reference_branches(E, g, s)
+    R.sweep(E)
+    for s, g in enumerate(gs):
+        assert R.grad_error(E, g, s) < 1e-5, (s, R.grad_error(E, g, s))
+
+
+def test_fresh_config3_scenes_against_the_cpu_step_oracle():
+    """64 stacks nobody has a golden for (seed 77) stepped three times on the device and, one by one, by oracle/step_oracle.c
+    (the reference's algorithm restated in C, Qhull through scipy): the ordered contact-pair list and the contact points of
+    every pair in every sub-step, poses 1e-7, velocities 1e-5."""
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.engine import BatchEngine
+    from oracle import step_oracle as SO
+    nS, T = 64, 3
+    spec = scenes.box_stack(nS, seed=77, floor_dims=(6.0, 1.0, 6.0), push=0.6)
+    E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=32, max_sub=8)
+    for _ in range(T):
+        E.step()
+    assert int(E.get("overflow").max()) == 0
+    shared = {0: (np.ascontiguousarray(spec["meshes"][0][0], np.float64), np.ascontiguousarray(spec["meshes"][0][1], np.int32))}
+    tp, tv, tnc, tb, tg = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_nc"), E.get("tp_body"), E.get("tp_geom")
+    worst = 0.0
+    for s in range(nS):
+        W = SO.World(spec, s, hull="scipy", shared=shared)
+        W.step(T)
+        assert W.nsub == int(E.get("nsub")[s]), (s, W.nsub, int(E.get("nsub")[s]))
+        for k in range(W.nsub):
+            t, pose, vel, (body, geom, _st, _lap) = W.substep(k)
+            if k + 1 < W.nsub:
+                p, v, n, bb, gg = tp[k + 1, s], tv[k + 1, s], int(tnc[k + 1, s]), tb[k + 1, s], tg[k + 1, s]
+            else:
+                p, v, n, bb, gg = E.get("pose")[s], E.get("vel")[s], int(E.get("nc")[s]), E.get("c_body")[s], E.get("c_geom")[s]
+            worst = max(worst, np.abs(p - pose).max())
+            assert np.abs(p - pose).max() < 1e-7 and np.abs(v - vel).max() < 1e-5, (s, k, np.abs(p - pose).max(), np.abs(v - vel).max())
+            assert [tuple(r) for r in bb[:, :n].T] == [tuple(r) for r in body], (s, k, "ordered contact-pair list differs")
+            for pair in sorted(set(map(tuple, body))):
+                m = (bb[:, :n].T == pair).all(axis=1); mr = (body == pair).all(axis=1)
+                a, b = gg[3:6, :n].T[m], geom[mr][:, 3:6]
+                ia = np.lexsort(np.round(a, 6).T[::-1]); ib = np.lexsort(np.round(b, 6).T[::-1])
+                assert np.abs(a[ia] - b[ib]).max() < 1e-6, (s, k, pair)
+        W.close()
+    print("64 fresh stacks: worst pose difference to the CPU oracle %.2e" % worst)
