@@ -99,36 +99,32 @@ def pmc_ratio(pmc, num, den, den_scale, *frags):
     return a / (den_scale * b) if b > 0 else None
 
 
-def cpu_baseline_lcp(E, n_sample, threads):
-    """Reference algorithm on the host: dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, a port of batch.py / lcp.py) on the
-    operands the GPU just solved, for a bounded sample of scenes; once on one thread, once with OpenMP over scenes."""
-    from oracle import lcp_expand as X
-    from oracle import lcp_oracle as O
-    O.build()
-    P = dict(Mblk=E.get("Mblk"), pvec=E.get("pvec"), A=E.get("Je"), bvec=np.zeros((E.B, E.neq)), cop=E.get("cop"),
-             cbody=E.get("cop_body"), nc=E.be.to_numpy(E.adj["bw_nc"]).copy(), nb=E.nb, neq=E.neq, maxc=E.maxc, fd=E.fd)
-    ncs = P["nc"]
-    pick = np.argsort(ncs)[len(ncs) // 2 - n_sample // 2: len(ncs) // 2 + (n_sample + 1) // 2]   # median-sized scenes
-    nineq_max = max(1, int(ncs[pick].max()) * (E.fd + 2))
-    ops = []
-    for s in pick:   # pad to a common nineq with inert rows (h = 1, G = 0) so one batched call covers them
-        Q, p, G, h, A, b, F = X.expand_dense(P, int(s))
-        k = nineq_max - len(h)
-        G = np.vstack([G, np.zeros((k, G.shape[1]))]); h = np.concatenate([h, np.ones(k)])
-        F = np.pad(F, ((0, k), (0, k)))
-        ops.append((Q, p, G, h, A, b, F))
-    Q, p, G, h, A, b, F = (np.stack(o) for o in zip(*ops))
+def cpu_baseline_step(spec, engine_kw, n_scenes, n_steps, threads):
+    """The reference's WHOLE time step on the host cores: oracle/step_oracle.c (broad phase, Frank-Wolfe search, contact
+    geometry, clustering + hull, assembly, dense PDIPM LCP forward, integration, accept / halve; plus the LCP's implicit
+    backward once per solve -- a C restatement of the reference's Python, pinned by its goldens) on the first `n_scenes`
+    scenes of THIS batch for `n_steps` steps from the start state: once on one thread (2 scenes), once with `threads` scenes
+    in flight.  Returns seconds per scene-step (1 thread), wall seconds per scene-step (all threads), the solver's share."""
+    from oracle import step_oracle as SO
+    SO.build()
+    floor = (np.ascontiguousarray(spec["meshes"][0][0], np.float64), np.ascontiguousarray(spec["meshes"][0][1], np.int32))
+    kw = dict(dt=engine_kw["dt"], eps=engine_kw["eps"], tol=engine_kw["tol"], fric_dirs=engine_kw["fric_dirs"],
+              strict_no_pen=engine_kw["strict_no_pen"], toc_diff=engine_kw["toc_diff"], hull="own", lcp_backward=True, shared={0: floor})
 
-    def run(nthreads, nscenes):
-        os.environ["OMP_NUM_THREADS"] = str(nthreads)
-        sl = slice(0, nscenes)
+    def run(nthreads, scenes):
+        ws = [SO.World(spec, s, **kw) for s in scenes]
         t0 = time.time()
-        z, lam, sl_, nu, it, st = O.forward(Q[sl], p[sl], G[sl], h[sl], A[sl], b[sl], F[sl], max_iter=10, check_spd=True)
-        O.backward(Q[sl], G[sl], A[sl], F[sl], z, lam, sl_, nu, np.ones_like(z))
-        return (time.time() - t0) / nscenes
-    one = run(1, min(2, len(pick)))            # seconds per scene, one thread
-    par = run(threads, len(pick))              # wall seconds per scene with `threads` scenes in flight
-    return one, par, len(pick), nineq_max
+        SO.run_many(ws, n_steps, nthreads)
+        wall = time.time() - t0
+        tm = [w.timers() for w in ws]
+        cn = [w.counters() for w in ws]
+        for w in ws:
+            w.close()
+        return wall / (len(ws) * n_steps), sum(t["solve"] for t in tm) / max(1e-30, sum(t["solve"] + t["detect"] for t in tm)), \
+            sum(c["lcp_rows"] for c in cn) / max(1, sum(c["lcp_solves"] for c in cn)), sum(c["attempts"] for c in cn) / (len(ws) * n_steps)
+    one, share, rows, att = run(1, list(range(min(2, n_scenes))))
+    par, _, _, _ = run(threads, list(range(n_scenes)))
+    return dict(one=one, par=par, lcp_share=share, lcp_rows=rows, attempts_per_step=att)
 
 
 def self_launch(n):
@@ -160,9 +156,12 @@ def build_engine(args, rank, dev):
     from diffsdfsim_amd.engine import BatchEngine, TorchBackend
     B, K, Wm, cfg = args.batch, args.steps, args.warmup, args.config
     be = TorchBackend(dev)
+    def keep(E, spec, strict):      # what the CPU baseline needs to step the same scenes (bench.py: cpu_baseline_step)
+        E.spec, E.spec_kw = spec, dict(dt=1.0 / 30, eps=1e-3, tol=1e-8, fric_dirs=8, strict_no_pen=strict, toc_diff=True)
+        return E
     if cfg == 2:
         spec = scenes.sphere_drop(B, seed=1000 + rank)
-        return BatchEngine(spec, maxc=64, max_cand=1024, max_pc=32, max_sub=4 * (K + Wm) + 64, backend=be)
+        return keep(BatchEngine(spec, maxc=64, max_cand=1024, max_pc=32, max_sub=4 * (K + Wm) + 64, backend=be), spec, True)
     if cfg == 3:
         spec = scenes.box_stack(B, nbox=args.nbox, seed=1000 + rank, push=args.push)
         # strict_no_pen=False as in the reference's own long-running experiments (optim_sysid.py:104-131): a scene
@@ -170,8 +169,8 @@ def build_engine(args, rank, dev):
         # retrying forever, which with strict=True stalls the reference as well.
         # (--push: boxes that slide and tip collect more contacts than the stack at rest; the larger capacity takes the
         # streaming variant of the LCP kernel, so that option is not the configuration the metric is quoted on)
-        return BatchEngine(spec, maxc=128 if args.push == 0.0 else 256, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16,
-                           strict_no_pen=False, backend=be)
+        return keep(BatchEngine(spec, maxc=128 if args.push == 0.0 else 256, max_cand=1024, max_pc=48, max_sub=int(1.5 * (K + Wm)) + 16,
+                                strict_no_pen=False, backend=be), spec, False)
     if cfg == 4:
         spec = scenes.igr_pole(B, seed=1000 + rank)
         return BatchEngine(spec, maxc=256, max_cand=8192, max_pc=128, max_sub=3 * (K + Wm) + 64, backend=be)
@@ -215,7 +214,7 @@ def bench_config1(args):
         "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                      "note": "one scene, a few 64-lane launches per step and a host decision after each: no roofline applies; the case is "
                              "in the suite for parity (tests/test_contacts2d_gpu.py), not for throughput"},
-        "cpu_baseline": {"value": 234.0, "unit": "steps/s", "cores": 1, "kind": "reference",
+        "cpu_baseline": {"value": None, "quoted_value": 234.0, "measured": False, "unit": "steps/s", "cores": 1, "kind": "reference",
                          "sample": "the reference itself on one core of the 8-vCPU build container (SURVEY.md section 6: 50 steps fwd+bwd of this "
                                    "scene); not timed on this host -- the reference cannot travel"}}))
 
@@ -228,7 +227,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU")
     ap.add_argument("--nbox", type=int, default=7)
-    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=32, help="scenes of the batch the CPU baseline steps (at least one per core)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="steps per sampled scene in the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
     args = ap.parse_args()
@@ -492,29 +493,30 @@ def main():
     if pmc_note:
         res["config"]["pmc_note"] = pmc_note
     if not args.no_cpu:
-        threads = min(os.cpu_count() or 1, args.cpu_sample)
-        if int(E.be.to_numpy(E.adj["bw_nc"]).max()) > 0:
-            one, par, ns, nineq = cpu_baseline_lcp(E, args.cpu_sample, threads)
-            gpu_lcp_share = float(lcp_ms.mean())    # + the backward LCP kernel, not timed separately (about 8 % of the forward's)
+        # host cores: this process's share of the box (a one-GPU box is given 16 cores' worth, whatever the affinity mask says)
+        threads = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        if cfg in (2, 3):
+            n_sc = min(B, max(threads, args.cpu_sample))
+            n_st = args.cpu_steps if cfg == 3 else 20 * args.cpu_steps      # (config 2: the spheres land after 4-12 steps; cover the bounces)
+            c = cpu_baseline_step(E.spec, E.spec_kw, n_sc, n_st, threads)
             res["cpu_baseline"] = {
-                "value": 1.0 / (B * par), "unit": "steps/s (LCP share only)", "cores": threads, "kind": "port",
-                "covers": "LCP forward+backward ONLY -- contact detection (half of the GPU step) has no CPU leg, so this is not a "
-                          "whole-step baseline and the ratio to `value` must not be quoted; compare with gpu_lcp_share_ms_per_step",
-                "lcp_s_per_scene_1_thread": one, "lcp_s_per_scene_wall_at_%d_threads" % threads: par,
-                "gpu_lcp_share_ms_per_step": gpu_lcp_share,
-                "reference_lapack_lcp_s_per_scene": {"value": 0.078, "where": "the reference's own torch/LAPACK LCPFunction fwd+bwd at nineq=560 "
-                                                     "on the 8-vCPU build container (SURVEY.md section 6); the plain-C port here is several "
-                                                     "times slower than that"},
-                "reference_whole_step_s_per_scene": {"value": 0.45, "where": "the reference itself (imported, torch CPU, float64), floor + 7-box stack with "
-                                                     "its own level-set meshes, 56 contacts, 3 steps forward + backward on the 8-vCPU build "
-                                                     "container: 2.2 scene-steps/s (SURVEY.md section 6).  Not timed on this host (the reference "
-                                                     "cannot travel); quoted so that the detection half of a CPU step has a size: about 0.37 s "
-                                                     "per scene-step outside the LCP"},
-                "sample": "dense PDIPM LCP fwd+bwd (oracle/lcp_oracle.c, the reference's algorithm, unblocked LU) on the operands of %d "
-                          "median scenes of this batch (nineq=%d), scaled to %d scenes" % (ns, nineq, B)}
+                "value": 1.0 / (B * c["par"]), "unit": "steps/s", "cores": threads, "kind": "port", "measured": True,
+                "scope": "whole step forward (detection + assembly + LCP + integration + accept/halve) + the LCP's implicit backward per solve",
+                "not_included": "the adjoint of the contact geometry / integration (torch autograd in the reference): the CPU figure is therefore an "
+                                "UPPER bound on a full fwd+bwd CPU rate, the GPU/CPU ratio a lower bound",
+                "s_per_scene_step_1_thread": c["one"], "wall_s_per_scene_step_at_%d_threads" % threads: c["par"],
+                "scene_steps_per_s_all_cores": 1.0 / c["par"], "lcp_share_of_cpu_time": c["lcp_share"], "lcp_rows_mean": c["lcp_rows"],
+                "attempts_per_step": c["attempts_per_step"],
+                "gpu_over_cpu_all_cores": (world * K / dt) * B * c["par"] / world,
+                "reference_python_s_per_scene_step": {"value": 0.45, "where": "the reference itself (imported, torch CPU + LAPACK, float64) on a floor + 7-box "
+                                                      "stack, forward + backward, one core of the 8-vCPU build container (SURVEY.md section 6); not timed "
+                                                      "on this host -- the reference cannot travel"},
+                "sample": "oracle/step_oracle.c + lcp_oracle.c (C port of the reference's step, blocked LU, OpenMP over scenes): the first %d scenes of "
+                          "this batch x %d steps from the start state, scaled to %d scenes (scenes are independent)" % (n_sc, n_st, B)}
         else:
-            res["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": threads, "kind": "port",
-                                   "sample": "no contacts in this workload at the end of the run: the dense-LCP port has nothing to time"}
+            res["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": threads, "kind": "port", "measured": False,
+                                   "sample": "the C port of the reference's step knows box / sphere / cylinder bodies pinned by TotalConstraint3D "
+                                             "(configs[1], configs[2]); it has no neural SDF body and no X/Y/Z constraint: no CPU leg for this config"}
     print(json.dumps(res))
 
 

@@ -166,8 +166,28 @@ class World3D(BatchWorld3D):
                  device=None, max_substeps=1024, full_kernels=None):
         if post_stab:
             raise NotImplementedError("post_stab (engines.py:85-121) is not built on the HIP path")
+        # The reference resolves `engine` / `contact_callback` by class or class name and calls them from inside step_dt
+        # (lcp_physics/physics/world.py:50-52, 259, 399).  Here one attempt of that loop -- assembly, LCP, integration, contact
+        # detection, accept / halve -- is ONE device call (dss_step_attempt), so only the device engine and the device contact
+        # handler can sit behind these two keywords; anything else is refused loudly instead of being silently replaced.
+        # (The plug-in seams themselves are served on the reference's side: its own World3D with engine=<a class calling
+        # dss_solve_dynamics> / contact_callback=<a handler calling dss_find_contacts>, INTEGRATION.md sections 2-3.)
         from . import engines as engines_module
-        self.engine_plugin = engine() if isinstance(engine, type) else getattr(engines_module, engine)()
+        cls = engine if isinstance(engine, type) else getattr(engines_module, str(engine), None)
+        if cls is None:
+            raise ValueError("unknown engine %r (known: PdipmEngine / HipPdipmEngine)" % (engine,))
+        if not (issubclass(cls, engines_module.HipPdipmEngine) and cls.solve_dynamics is engines_module.HipPdipmEngine.solve_dynamics):
+            raise NotImplementedError(
+                "World3D(engine=%s): this world steps on the device engine, whose solve / move / detect / accept loop is one call per "
+                "attempt; a custom Engine.solve_dynamics(world, dt) cannot be called from inside it.  Use the reference's World3D with "
+                "an engine that wraps dss_solve_dynamics (INTEGRATION.md section 2) if a custom engine is needed." % getattr(cls, "__name__", cls))
+        cb = contact_callback if isinstance(contact_callback, str) else getattr(contact_callback, "__name__", type(contact_callback).__name__)
+        if cb != Defaults3D.CONTACT:
+            raise NotImplementedError(
+                "World3D(contact_callback=%s): contacts are found by the device narrow phase (the reference's FWContactHandler, "
+                "contacts.py:27-272); another handler cannot be called from inside the device step.  Use the reference's World3D with "
+                "a handler that wraps dss_find_contacts (INTEGRATION.md section 3)." % cb)
+        self.engine_plugin = cls()
         self.bodies = bodies
         self.vec_len = 6
         nb = len(bodies)
@@ -270,23 +290,26 @@ class World3D(BatchWorld3D):
         had = bool(BatchWorld3D.step(self, fixed_dt)[0])
         self._t = float(self.engine.get("t")[0])
         self._sync_bodies()
-        # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-377 appends them, one entry per ACCEPTED
-        # sub-step (step(fixed_dt=True) loops step_dt until the full dt has passed, world.py:119-139).  The sub-steps inside
-        # one outer step are read back from the tape (values: only the state at the end of the call is connected to the graph)
+        # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-379 appends them: one entry per ACCEPTED
+        # sub-step (step(fixed_dt=True) loops step_dt until the full dt has passed, world.py:119-139), appended BEFORE
+        # `self.t += dt` -- an entry carries the time at the START of its sub-step together with the state and contacts AFTER it.
+        # The sub-steps inside one outer step are read back from the tape (values: only the state at the end of the call is
+        # connected to the graph)
         n1 = int(E.get("nsub")[0])
+        t = t0
         if n1 - n0 > 1 and n1 <= int(E.W.max_sub):
             tp, tv, tdt = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_dt")
             tnc, tb, tg = E.get("tp_nc"), E.get("tp_body"), E.get("tp_geom")
-            t = t0
             for j in range(n0, n1 - 1):          # the state after sub-step j = the start of sub-step j + 1
-                t += float(tdt[j, 0])
                 cs = []
                 for c in range(int(tnc[j + 1, 0])):
                     g_, b_ = tg[j + 1, 0], tb[j + 1, 0]
                     tt = lambda a: torch.tensor(a.copy())
                     cs.append(((tt(g_[0:3, c]), tt(g_[3:6, c]), tt(g_[6:9, c]), tt(g_[9, c])), int(b_[0, c]), int(b_[1, c])))
                 self.trajectory.append((t, torch.tensor(tp[j + 1, 0].reshape(-1)), torch.tensor(tv[j + 1, 0].reshape(-1)), cs, None))
-        self.trajectory.append((self._t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), self.contacts, None))
+                t += float(tdt[j, 0])
+            t = self._t - float(tdt[n1 - 1, 0])      # start of the last sub-step
+        self.trajectory.append((t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), self.contacts, None))
         return had
 
     def get_v(self):

@@ -72,6 +72,16 @@ def install(device="cpu"):
     sys.modules.setdefault("ev_sdf_utils", fake_ev_sdf_utils)
     for name in ("pygame", "cvxpy", "pyrender", "pyhocon"):
         sys.modules.setdefault(name, _inert(name))
+    from . import fake_sacred      # experiment scripts (sacred decorators, tensorboard writer) import and stay callable
+    sys.modules.setdefault("sacred", fake_sacred)
+    sys.modules.setdefault("sacred.utils", fake_sacred.utils)
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        sys.modules["torch.utils.tensorboard"] = _inert("torch.utils.tensorboard", ["SummaryWriter"])
+    exp = os.path.join(REFERENCE_ROOT, "experiments", "trajectory_fitting")
+    if exp not in sys.path:
+        sys.path.append(exp)
     os.environ.setdefault("IGR_PATH", "/tmp")
     os.environ.setdefault("PYOPENGL_PLATFORM", "egl")
     if REFERENCE_ROOT not in sys.path:

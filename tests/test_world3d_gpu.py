@@ -41,6 +41,29 @@ def test_world3d_rollout_and_gradient_match_reference(name, toc):
     assert abs(float(rad.grad) - float(g["grad_0"])) < 1e-5 * abs(float(g["grad_0"])) + 1e-9, (rad.grad, g["grad_0"])
 
 
+def test_world3d_trajectory_entries_are_the_references():
+    """`world.trajectory` as lcp_physics/physics/world.py:373-379 builds it: one entry per ACCEPTED sub-step, appended before
+    `self.t += dt`, i.e. stamped with the time at the START of the sub-step and holding the state AFTER it (the experiments'
+    `trajectory_loss`, optim_sphere.py:114-160, pairs entries by these times and divides by their number).  Sphere drop with
+    time-of-contact events: 37 entries for 24 steps; times, poses and velocities against the reference's list, and the
+    `undo_step` quirk that the undone step's first entry survives (`while self.trajectory[-1][0] > self.t`, world.py:114-116)."""
+    g = R.load_rollout("rollout_sphere")
+    w, floor, ball, rad = build_sphere_world(g, toc=True)
+    for _ in range(24):
+        w.step(fixed_dt=True)
+    assert len(w.trajectory) == len(g["traj_t"])
+    assert len(g["traj_t"]) > 24, "the scene was meant to halve dt"
+    for e, t, p, v in zip(w.trajectory, g["traj_t"], g["traj_p"], g["traj_v"]):
+        assert abs(float(e[0]) - float(t)) < 1e-12, (float(e[0]), float(t))
+        assert np.abs(e[1].detach().cpu().numpy().reshape(2, 7) - p).max() < 1e-7 and np.abs(e[2].detach().cpu().numpy().reshape(2, 6) - v).max() < 1e-7
+    n = len(w.trajectory)
+    t_before = w.t
+    w.step(fixed_dt=True)
+    added = len(w.trajectory) - n
+    w.undo_step()
+    assert w.t == t_before and len(w.trajectory) == n + 1 and added >= 1      # the entry stamped t_before stays, as in the reference
+
+
 def test_world3d_step_without_fixed_dt_and_run_world():
     from diffsdfsim_amd.physics3d import run_world
     g = R.load_rollout("rollout_sphere_notoc")
