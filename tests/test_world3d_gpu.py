@@ -45,14 +45,14 @@ def test_world3d_trajectory_entries_are_the_references():
     """`world.trajectory` as lcp_physics/physics/world.py:373-379 builds it: one entry per ACCEPTED sub-step, appended before
     `self.t += dt`, i.e. stamped with the time at the START of the sub-step and holding the state AFTER it (the experiments'
     `trajectory_loss`, optim_sphere.py:114-160, pairs entries by these times and divides by their number).  Sphere drop with
-    time-of-contact events: 37 entries for 24 steps; times, poses and velocities against the reference's list, and the
+    time-of-contact events: 245 entries for 100 steps; times, poses and velocities against the reference's list, and the
     `undo_step` quirk that the undone step's first entry survives (`while self.trajectory[-1][0] > self.t`, world.py:114-116)."""
-    g = R.load_rollout("rollout_sphere")
+    g = R.load_rollout("rollout_sphere_long")
     w, floor, ball, rad = build_sphere_world(g, toc=True)
-    for _ in range(24):
+    for _ in range(100):
         w.step(fixed_dt=True)
     assert len(w.trajectory) == len(g["traj_t"])
-    assert len(g["traj_t"]) > 24, "the scene was meant to halve dt"
+    assert len(g["traj_t"]) > 100, "the scene was meant to halve dt"
     for e, t, p, v in zip(w.trajectory, g["traj_t"], g["traj_p"], g["traj_v"]):
         assert abs(float(e[0]) - float(t)) < 1e-12, (float(e[0]), float(t))
         assert np.abs(e[1].detach().cpu().numpy().reshape(2, 7) - p).max() < 1e-7 and np.abs(e[2].detach().cpu().numpy().reshape(2, 6) - v).max() < 1e-7
@@ -117,7 +117,9 @@ def test_undo_step_set_p_set_v():
     p1, v1, t1 = w.pose.clone(), w.v.clone(), w.t
     w.undo_step()
     assert w.t == t0 and torch.equal(w.pose, p0) and torch.equal(w.v, v0)
-    assert len(w.contacts) == nc0 and len(w.trajectory) == ntraj and torch.equal(ball.p, p0[0, 1])
+    # the trajectory keeps the undone step's FIRST entry, as in the reference: entries are stamped with the start time of their
+    # sub-step and undo_step pops `while self.trajectory[-1][0] > self.t` (world.py:114-116) -- that entry's stamp equals self.t
+    assert len(w.contacts) == nc0 and len(w.trajectory) == ntraj + 1 and torch.equal(ball.p, p0[0, 1])
     w.step(fixed_dt=True)
     assert w.t == t1 and torch.equal(w.pose, p1) and torch.equal(w.v, v1)
     nv = w.v.clone(); nv[9] = 0.25                      # give the ball a push along x
