@@ -127,14 +127,38 @@ def cpu_baseline_step(spec, engine_kw, n_scenes, n_steps, threads):
     return dict(one=one, par=par, lcp_share=share, lcp_rows=rows, attempts_per_step=att)
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT touching HIP (the launcher parent must stay uninitialised: it starts
+    children).  ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES if set, else the GPU nodes of the KFD topology
+    (nodes with SIMDs; CPU nodes have simd_count 0)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n, top = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(top):
+            try:
+                txt = open(os.path.join(top, d, "properties")).read()
+            except OSError:
+                continue
+            for line in txt.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return 0
+    return n
+
+
 def self_launch(n):
     """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same variables
-    torch.distributed.run sets), same argv.  With fewer visible GPUs than ranks the ranks share devices and the
-    collectives go through gloo (a rehearsal of the same code path, flagged in the JSON line)."""
+    torch.distributed.run sets), same argv.  The parent never imports torch and never touches HIP.  With fewer visible GPUs
+    than ranks the ranks share devices and the collectives go through gloo (a rehearsal of the same code path, flagged in the
+    JSON line).  The children are polled: when one dies the others are terminated instead of waiting in a rendezvous or a
+    barrier for the process-group timeout."""
     import socket
     import subprocess
-    import torch   # importing torch and counting devices does not initialise the GPU
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpus()
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -146,8 +170,23 @@ def self_launch(n):
             env.setdefault("DSS_DIST_BACKEND", "gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+                for q in live:          # exactly the children started above
+                    q.terminate()
     for p in procs:
-        rc = max(rc, abs(p.wait()))
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 
@@ -245,6 +284,8 @@ def main():
         # this process touches the GPU (no exec of an initialised process); rank 0's JSON line is the children's stdout
         sys.exit(self_launch(args.gpus))
 
+    if os.environ.get("DSS_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and "WORLD_SIZE" in os.environ:
+        sys.exit(7)      # tests/test_bench_launcher.py: a rank that dies before the rendezvous
     import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -262,7 +303,8 @@ def main():
             torch.cuda.set_device(local % torch.cuda.device_count())     # RCCL binds its communicator to the current device
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("DSS_DIST_TIMEOUT", 180))), **kw)
         if os.environ.get("DSS_BENCH_DRYRUN"):   # launcher + rendezvous check without a GPU (tests/test_bench_launcher.py)
             mine = torch.tensor([rank], dtype=torch.int64)
             got = [torch.empty_like(mine) for _ in range(world)]
@@ -305,13 +347,13 @@ def main():
     E.backward_sweep(att)
 
     def gather_results():
-        # "final trivial gather" of the shard results: final poses and the per-scene parameter gradients
+        # "final trivial gather" of the shard results: final poses and the per-scene parameter gradients,
+        # through the same diffsdfsim_amd.sharding.gather_scenes that tests/test_shard_cpu.py checks over gloo
+        from diffsdfsim_amd import sharding
         final = torch.cat([E.arr["pose"].reshape(B, -1), E.adj["g_prm"].reshape(B, -1), E.adj["g_mass"].reshape(B, -1),
                            E.adj["g_fric"].reshape(B, -1)], dim=1)
         if dist is not None:
-            fin = final.to(cdev)
-            out = [torch.empty_like(fin) for _ in range(world)]
-            dist.all_gather(out, fin)
+            return sharding.gather_scenes(final.to(cdev), B * world, dist)
         return final
     gather_results()      # part of the warm-up: the first concatenation loads its kernel, the first collective sets up its channels
     torch.cuda.synchronize()

@@ -249,6 +249,11 @@ template <class T> __host__ __device__ inline void load_body(const Args2D &A, in
 {
     const size_t o = (size_t)s * A.P + p;
     b.kind = A.kind[o]; b.nv = A.nv[o];
+    // the C ABI hands these in from device memory: a vertex count beyond the table (MAXV, maxv) would index past v[][] in every
+    // loop over the polygon -- clamp it (the forward kernel reports such a pair with count = -1, as it does an unknown kind)
+    if (b.nv > MAXV) b.nv = MAXV;
+    if (b.nv > A.maxv) b.nv = A.maxv;
+    if (b.nv < 0) b.nv = 0;
     b.pos[0] = T(A.pos[2 * o]); b.pos[1] = T(A.pos[2 * o + 1]);
     b.rad = T(A.rad[o]);
     for (int i = 0; i < MAXV; ++i)
@@ -264,6 +269,17 @@ __global__ void __launch_bounds__(64) contacts2d_forward_kernel(Args2D A, int *s
     load_body(A, p, 1, b2);
     int s1 = A.sat_in[p], s2 = A.sat_in[A.P + p];
     Contact2<double> c[2];
+    auto bad = [&](int s) {
+        const size_t o = (size_t)s * A.P + p;
+        const int k = A.kind[o], nv = A.nv[o];
+        return (k != 0 && k != 1) || nv < 0 || nv > MAXV || nv > A.maxv;
+    };
+    if (bad(0) || bad(1)) {      // malformed pair: flagged, no contact written
+        count[p] = -1;
+        sat_out[p] = s1; sat_out[A.P + p] = s2;
+        for (int q = 0; q < 14; ++q) out[(size_t)p * 14 + q] = 0.0;
+        return;
+    }
     const int n = pair_contacts(b1, b2, A.eps, s1, s2, c);
     count[p] = n;
     sat_out[p] = s1; sat_out[A.P + p] = s2;

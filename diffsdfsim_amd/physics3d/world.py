@@ -108,11 +108,13 @@ class BatchWorld3D:
 
     _UNDO_ARRAYS = ("t", "nc", "c_body", "c_face", "c_abc", "c_geom", "last_dt", "toc", "nsub")
 
-    def step(self, fixed_dt=True, mask=None):
+    def step(self, fixed_dt=True, mask=None, keep_undo=True):
         """One outer step for every scene, or with `mask` ([B] booleans) for the selected scenes only (the others keep their
-        state and time).  Returns [B] booleans: contacts present afterwards (World.step's `had_contacts`, world.py:119-139)."""
+        state and time).  Returns [B] booleans: contacts present during the step (World.step's `had_contacts`, world.py:119-139;
+        False for scenes the mask left out).  keep_undo=False skips the snapshot `undo_step` needs (nine device copies per step,
+        the contact arrays among them) for callers that never undo."""
         E = self.engine
-        self._start_batch = (self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS})
+        self._start_batch = (self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}) if keep_undo else None
         if mask is not None:
             mask = np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(np.int32)
         P = self.params
@@ -132,11 +134,14 @@ class BatchWorld3D:
                                             to("verts", P["verts"]) if P.get("verts") is not None else None, mask)
         up = self.__dict__.setdefault("_uploaded", {})
         up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
-        return self.engine.get("had_contacts") > 0
+        had = self.engine.get("had_contacts") > 0
+        return had if mask is None else had & (mask > 0)      # (the kernel clears the flag of stepped scenes only)
 
     def undo_step(self, mask):
         """`World.undo_step` (lcp_physics/physics/world.py:106-116) for the scenes `mask` selects: time, poses, velocities
         (with their graph) and contacts go back to the start of the last step; the other scenes keep what they have."""
+        if self._start_batch is None:
+            raise RuntimeError("undo_step(): the last step was taken with keep_undo=False")
         pose0, vel0, arrs = self._start_batch
         m = torch.as_tensor(np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(bool), device=self.device)
         E = self.engine
@@ -287,7 +292,7 @@ class World3D(BatchWorld3D):
         E = self.engine
         self._start = (self._t, self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}, self._n_nodes)
         n0, t0 = int(E.get("nsub")[0]), self._t
-        had = bool(BatchWorld3D.step(self, fixed_dt)[0])
+        had = bool(BatchWorld3D.step(self, fixed_dt, keep_undo=False)[0])      # (World3D keeps its own snapshot, above)
         self._t = float(self.engine.get("t")[0])
         self._sync_bodies()
         # (t, p, v, contacts, joint rotations) as lcp_physics/physics/world.py:373-379 appends them: one entry per ACCEPTED

@@ -401,6 +401,8 @@ int dss_meshsdf_backward(int shape_type, const double *unit_prm, const double *u
  *   backward: gout [P][2][7] (rows >= count ignored) -> g_pos [2][P][2], g_rad [2][P], g_verts [2][P][maxv][2], with the
  *     sat_in the forward started from (the branch decisions are taken on values, as the reference takes them on .item()). */
 #define DSS_C2D_MAXV 8
+/* (a pair whose kind is neither 0 nor 1, or whose vertex count is negative or exceeds maxv / the compiled table of 8, is reported
+ *  with count = -1 and writes no contact; the backward pass clamps such counts and returns zeros for what it cannot read) */
 int dss_contacts2d_forward(int npairs, int maxv, const int *kind, const int *nv, const double *pos, const double *rad,
                            const double *verts, const int *sat_in, double eps, int *sat_out, int *count, double *out,
                            void *stream);

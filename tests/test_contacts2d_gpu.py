@@ -245,3 +245,24 @@ def test_general_hulls_end_to_end_against_the_reference_world():
     gs, = torch.autograd.grad(loss, [sc])
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-8 * abs(float(g["loss"]))
     assert abs(float(gs) - float(g["g_scale"])) < 1e-5 * abs(float(g["g_scale"])), (float(gs), float(g["g_scale"]))
+
+
+def test_malformed_pairs_are_flagged_not_read_out_of_bounds():
+    """The public C ABI takes `kind` and `nv` from device memory: a vertex count beyond the table or an unknown kind must not
+    index past the per-lane vertex array -- such a pair comes back with count = -1 and no contact, its neighbours untouched."""
+    import torch
+    from diffsdfsim_amd.physics2d.contacts import contacts2d
+    dev = torch.device("cuda:0")
+    P, maxv = 4, 8
+    pos = torch.zeros(2, P, 2, dtype=torch.float64, device=dev); pos[1, :, 0] = 1.5
+    rad = torch.ones(2, P, dtype=torch.float64, device=dev)
+    verts = torch.zeros(2, P, maxv, 2, dtype=torch.float64, device=dev)
+    kind = torch.zeros(2, P, dtype=torch.int32, device=dev)
+    nv = torch.zeros(2, P, dtype=torch.int32, device=dev)
+    sat = torch.zeros(2, P, dtype=torch.int32, device=dev)
+    kind[0, 1] = 1; nv[0, 1] = 1000            # polygon with an absurd vertex count
+    kind[1, 2] = 7                             # unknown kind
+    out, count, _ = contacts2d(pos, rad, verts, kind, nv, sat, 0.1)
+    c = count.cpu().numpy()
+    assert c[0] == 1 and c[3] == 1 and c[1] == -1 and c[2] == -1, c
+    assert float(out[1].abs().max()) == 0.0 and float(out[2].abs().max()) == 0.0 and float(out[0].abs().max()) > 0.0
