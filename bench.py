@@ -258,6 +258,85 @@ def bench_config1(args):
                                    "scene); not timed on this host -- the reference cannot travel"}}))
 
 
+def bench_config5(args, dist, rank, world, dev, cdev, backend):
+    """BASELINE configs[4] as the reference runs it (experiments/inertia_fitting/optim_shapespace.py:71-92, 136-250): EVERY
+    optimisation iteration rebuilds the world from the latent codes -- latent -> 128^3 samples of the network (fp64 matrix cores)
+    -> marching cubes -> inertia by volume integrals over the mesh -> single-body scene with X/Y/Z constraints -> 200 steps with a
+    torque along a random direction for t < 0.3 -> loss on the final angular velocity -> backward to the latent (reverse sweep,
+    inertia adjoint, MeshSDF).  One timed "iteration" = that whole chain for B scenes; a "step" = one of its K simulation steps.
+    Trajectories (K, B, 13) are gathered at the end, as north_star says."""
+    import torch
+    from diffsdfsim_amd import experiments as X
+    from diffsdfsim_amd import igr, meshsdf, scenes, sharding
+    B, K = args.batch, args.steps
+    torch.cuda.set_device(dev)
+    packed = igr.pack_weights(*scenes.geometric_init_weights(0, 0.5), device=dev)
+    r = np.random.default_rng(1000 + rank)
+    lat0 = 0.1 * r.standard_normal((B, 2))
+    dirs = r.standard_normal((B, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dt = 1.0 / 30
+
+    def iteration(nsc, record):
+        lat = torch.tensor(lat0[:nsc], dtype=torch.float64, requires_grad=True)
+        meshsdf.GRID_EVENTS = [] if record else None
+        t = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        w = X.spin_world(lat, dirs[:nsc], packed, scale=1.0, mass=1.0, res=args.res, steps=K, device=dev, keep_meshes=False)
+        torch.cuda.synchronize(); t["build_s"] = time.perf_counter() - t0
+        tq = torch.cat([torch.as_tensor(0.5 * dirs[:nsc]), torch.zeros(nsc, 3, dtype=torch.float64)], 1)[:, None]
+        traj = []
+        for k in range(K):
+            w.params["fext"] = tq if k * dt < 0.3 else torch.zeros_like(tq)      # the torque stops at t = 0.3 (optim_shapespace.py:83-88)
+            w.step(keep_undo=False)
+            traj.append(torch.cat([w.pose[:, 0], w.vel[:, 0]], dim=1))
+        torch.cuda.synchronize(); t["spin_s"] = time.perf_counter() - t0 - t["build_s"]
+        loss = (w.vel[:, 0, :3] ** 2).sum()
+        loss.backward()
+        torch.cuda.synchronize(); t["backward_s"] = time.perf_counter() - t0 - t["build_s"] - t["spin_s"]
+        tr = torch.stack(traj, dim=1).reshape(nsc, -1)                            # [B, K * 13]
+        if dist is not None:
+            tr = sharding.gather_scenes(tr.to(cdev), nsc * world, dist)
+        torch.cuda.synchronize(); t["total_s"] = time.perf_counter() - t0
+        ev, meshsdf.GRID_EVENTS = meshsdf.GRID_EVENTS, None
+        return t, ev, lat.grad, [m[1] if isinstance(m[1], int) else len(m[1]) for m in w.meshes]
+    for _ in range(max(1, min(args.warmup, 1))):
+        iteration(min(B, 8), False)                  # warm-up: the same chain on eight scenes (kernels loaded, allocator primed)
+    if dist is not None:
+        dist.barrier()
+    t, ev, grad, nfaces = iteration(B, True)
+    tot = t["total_s"]
+    if dist is not None:
+        tt = torch.tensor([tot], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tot = float(tt.item())
+    if rank != 0:
+        return
+    ms = np.array([a.elapsed_time(b) for a, b, _n in ev])
+    pts = float(sum(n for _a, _b, n in ev))
+    flops = 2.0 * IGR_MAC_PER_POINT * pts
+    ach = flops / (ms.sum() * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "sim steps/sec (fwd+bwd), BASELINE configs[4]", "value": world * K / tot, "unit": "steps/s", "n_gpus": world, "steps": K,
+        "warmup": args.warmup, "ms_per_step": 1e3 * tot / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "configs[4]: inertia fitting in shape space, %d scenes per GPU: per iteration latent -> %d^3 network grid -> marching cubes "
+                               "-> mesh inertia -> %d-step spin (torque for t < 0.3, no contacts) -> reverse sweep to the latent" % (B, args.res, K),
+                   "scenes_per_gpu": B, "grid_res": args.res, "mesh_faces_mean": float(np.mean(nfaces)),
+                   "world_build_s": t["build_s"], "spin_forward_s": t["spin_s"], "backward_s": t["backward_s"], "iteration_s": tot,
+                   "scene_steps_per_s": world * B * K / tot, "latent_grad_finite": bool(torch.isfinite(grad).all()), "lib_sha256": lib_hash(),
+                   "parallelism": "scene-sharded x%d; one all_gather (%s) of the (K, B, 13) trajectories" % (world, backend or "none")},
+        "roofline": {"bound": "mfma", "kernel": "igr_query_kernel, value-only (fp64 v_mfma_f64_16x16x4): the %d^3 grid of every scene's level-set mesh" % args.res,
+                     "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                     "avg_launch_ms": float(ms.mean()), "launches": len(ms), "algorithmic_flops_per_launch": flops / len(ms),
+                     "share_of_iteration": float(ms.sum() * 1e-3 / tot),
+                     "note": "flops = 2 x 115456 MAC per grid point; HIP events around every grid evaluation of the timed iteration"},
+        "roofline_second_kernel": {"bound": "latency", "kernel": "stepper, contact-free branch (assemble / 9x9 solve / integrate / decide)", "achieved": None,
+                                   "peak": None, "unit": None, "frac": None, "traffic": None, "ms_per_step": 1e3 * t["spin_s"] / K,
+                                   "note": "six small launches per step: launch-bound (python bench.py --config 5 --spin-only times it alone)"},
+        "cpu_baseline": {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "measured": False,
+                         "sample": "no CPU leg: the C port of the reference's step has no neural SDF, marching cubes or X/Y/Z constraints"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +350,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
+    ap.add_argument("--spin-only", action="store_true", help="config 5: time only the 200-step spin of given inertias (round 2's line), "
+                    "not the per-iteration rebuild latent -> 128^3 network grid -> marching cubes -> inertia")
+    ap.add_argument("--res", type=int, default=128, help="config 5: grid resolution of the level-set mesh (the reference: 128)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = DEFAULTS[args.config]["steps"]
@@ -325,6 +407,8 @@ def main():
     from diffsdfsim_amd import world_abi as abi
     _lib.lib()   # fail loudly if the HIP library is missing
 
+    if args.config == 5 and not args.spin_only:
+        return bench_config5(args, dist, rank, world, dev, cdev, backend)
     B, K, Wm, cfg = args.batch, args.steps, args.warmup, args.config
     t_build = time.time()
     E = build_engine(args, rank, dev)

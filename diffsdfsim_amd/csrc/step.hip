@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
             }
             if (lane == 0) {
                 W.tp_dt[rec] = W.dt_use[sc]; W.tp_nc[rec] = nc_old;
+                if (W.tp_t) W.tp_t[rec] = W.t[sc];
                 W.tp_flags[rec] = ((W.toc_diff && toc && !escaped) ? 1 : 0) | ((W.toc_diff && W.toc[sc]) ? 2 : 0);
             }
         }

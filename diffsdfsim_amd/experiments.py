@@ -56,10 +56,15 @@ def rollout(world, steps):
 
 
 def run_world_fixed_dt(world, run_time, detach_2nd_bounce=False, max_steps=10000):
-    """`run_world_fixed_dt` (optim_sphere.py:163-177) per scene of a batch.  Returns the trajectory as a dict of
-    t [K,B], pose [K,B,nb,7], vel [K,B,nb,6], valid [K,B]: entry k of scene s is valid if the scene took outer step k and the
-    step was not undone (an undone step is dropped from the reference's trajectory list, world.py:106-116)."""
+    """`run_world_fixed_dt` (optim_sphere.py:163-177) per scene of a batch.  Returns the trajectory as the reference's
+    `world.trajectory` holds it, as a dict of t [K,B], pose [K,B,nb,7], vel [K,B,nb,6], valid [K,B]: ONE ENTRY PER ACCEPTED
+    SUB-STEP (a step that halves dt or goes through a time-of-contact event adds several), stamped with the time at the START
+    of the sub-step and holding the state after it (world.py:373-379: the entry is appended before `self.t += dt`); every entry
+    keeps its graph.  An undone step (detach_2nd_bounce) leaves the list -- except its first entry: `undo_step` pops
+    `while self.trajectory[-1][0] > self.t` (world.py:114-116) and that entry's stamp EQUALS self.t, so it stays, un-detached,
+    as it does in the reference."""
     B, dev = world.B, world.device
+    world.record_substeps = True
     num_contact = np.zeros(B, np.int64)
     T, P, V, OK = [], [], [], []
     for _ in range(max_steps):
@@ -68,6 +73,7 @@ def run_world_fixed_dt(world, run_time, detach_2nd_bounce=False, max_steps=10000
         if not mask.any():
             break
         had = np.asarray(world.step(mask=mask)) & mask
+        sub, pose_end, vel_end = world.substeps, world.pose, world.vel
         redo = np.zeros(B, bool)
         if detach_2nd_bounce:
             num_contact += had
@@ -76,18 +82,27 @@ def run_world_fixed_dt(world, run_time, detach_2nd_bounce=False, max_steps=10000
                 world.undo_step(redo)
                 world.detach_state(redo)
                 num_contact[redo] = 0
-        T.append(torch.as_tensor(world.t.copy(), device=dev)); P.append(world.pose); V.append(world.vel)
-        OK.append(torch.as_tensor(mask & ~redo, device=dev))
+        m_t = torch.as_tensor(mask, device=dev); r_t = torch.as_tensor(redo, device=dev)
+        K = int(sub["pose"].shape[0])
+        for k in range(K):           # the sub-steps inside this outer step
+            T.append(sub["t"][k]); P.append(sub["pose"][k]); V.append(sub["vel"][k])
+            OK.append(sub["valid"][k] & m_t & (~r_t if k > 0 else torch.ones_like(r_t)))
+        # the last sub-step's entry = the state the step ended in; of an undone step it survives only if it is the step's FIRST entry
+        first_is_last = ~sub["valid"][0] if K > 0 else torch.ones(B, dtype=torch.bool, device=dev)
+        T.append(sub["last_t"]); P.append(pose_end); V.append(vel_end)
+        OK.append(m_t & (~r_t | first_is_last))
     return dict(t=torch.stack(T), pose=torch.stack(P), vel=torch.stack(V), valid=torch.stack(OK))
 
 
 def trajectory_loss(traj, target, body=-1):
     """optim_sphere.py:114-160: every entry of a scene's trajectory is compared with the target entry nearest in time (position
-    of the last body; the sum over the scene's entries divided by their number).  -> [B]"""
+    of the last body); the sum over the scene's entries divided by their number.  Of two target entries equally near the LATER
+    one is taken (`if diff <= min_diff`, :131).  -> [B]"""
     tw, tt = traj["t"], target["t"].to(traj["t"])
     diff = (tw[:, None, :] - tt[None, :, :]).abs()                                                             # [Kw, Kt, B]
     diff = torch.where(target["valid"].to(tw.device)[None, :, :], diff, torch.full_like(diff, float("inf")))
-    j = diff.argmin(dim=1)                                                                                      # [Kw, B]
+    Kt = diff.shape[1]
+    j = Kt - 1 - diff.flip(1).argmin(dim=1)                                                                     # [Kw, B], last of the minima
     pos_t = target["pose"][:, :, body, 4:].to(traj["pose"])
     near = torch.gather(pos_t, 0, j[:, :, None].expand(-1, -1, 3))
     d = traj["pose"][:, :, body, 4:] - near
@@ -309,7 +324,7 @@ def fit_trajectory_latent(target_latents, start_latents, packed, run_time=1.0, m
 
 
 # ---- inertia fitting: a neural-SDF body spun by a torque (optim_shapespace.py) ------------------------------------------------
-def spin_world(latents, torque_dirs, packed, scale=1.0, mass=1.0, res=128, steps=64, device=None):
+def spin_world(latents, torque_dirs, packed, scale=1.0, mass=1.0, res=128, steps=64, device=None, keep_meshes=True):
     """optim_shapespace.py:71-92 for one scene per latent code: a single neural-SDF body (scale 1) whose translation is locked
     by X/Y/Z constraints; no contacts, so only its inertia matters -- integrated over its level-set mesh (MeshSDF:
     differentiable w.r.t. the latent).  The torque (t < 0.3) is applied by the caller through world.params['fext']."""
@@ -318,8 +333,10 @@ def spin_world(latents, torque_dirs, packed, scale=1.0, mass=1.0, res=128, steps
     for s in range(B):
         v, f = meshsdf.igr_mesh(latents[s], packed, res=res)
         vt = v * scale
-        Is.append(mass_properties.mesh_inertia_diff(vt, f, torch.tensor(float(mass), dtype=torch.float64)).cpu())
-        ms.append((vt.detach().cpu().numpy(), f.cpu().numpy()))
+        Is.append(mass_properties.mesh_inertia_diff(vt, f, torch.tensor(float(mass), dtype=torch.float64)))
+        # (the meshes are only kept for the chamfer distance of the experiment's report; a caller that does not need them saves
+        # a device -> host copy of ~1 MB and a synchronisation per scene)
+        ms.append((vt.detach().cpu().numpy(), f.cpu().numpy()) if keep_meshes else (None, int(f.shape[0])))
     return _spin_world(torch.stack(Is), ms, scale, mass, steps, device)
 
 
@@ -329,7 +346,7 @@ def _spin_world(inertias, ms, scale, mass, steps, device):
     inertia = inertias[:, None]                                               # [B,1,3,3], graph to the shape parameters
     one = lambda a: np.tile(np.asarray(a, np.float64), (B, 1, 1))
     spec = dict(pose=one([1.0, 0, 0, 0, 0, 0, 0]), vel=one(np.zeros(6)), mass=np.full((B, 1), float(mass)),
-                inertia=inertia.detach().numpy(), restitution=np.zeros((B, 1)), fric=np.zeros((B, 1)), fext=np.zeros((B, 1, 6)),
+                inertia=inertia.detach().cpu().numpy(), restitution=np.zeros((B, 1)), fric=np.zeros((B, 1)), fext=np.zeros((B, 1, 6)),
                 shape_type=np.full((B, 1), abi.SHAPE_SPHERE, np.int32), shape_prm=one([scale, 0, 0]),      # (nothing collides: the shape is never queried)
                 # (a lone body per scene: the stepper never searches its mesh, so it gets one shared triangle instead of B
                 # level-set meshes of 10^5 faces whose search structures would take seconds to build; the real meshes stay on

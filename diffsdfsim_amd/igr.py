@@ -49,6 +49,26 @@ def igr_query(pts, latent, P, wrt="xyz"):
     return sdf, grad
 
 
+class _Net(ctypes.Structure):      # DssIgrNet (include/diffsdfsim_hip.h)
+    _fields_ = [(k, ctypes.c_void_p) for k in ("W0", "b0", "Wp", "bh", "W8", "b8")]
+
+
+def igr_values(pts, latent, P):
+    """Values only (query_sdfs with return_grads=False): pts [n,3], latent [2] -> sdf [n].  A quarter of the matrix work of
+    `igr_query` (no tangents) -- what sampling the 128^3 grid of a level-set mesh needs (bodies.py:657-664)."""
+    _lib.require_device(pts, latent)
+    L = _lib.lib()
+    n = pts.shape[0]
+    sdf = torch.empty(n, dtype=torch.float64, device=pts.device)
+    net = _Net(*[P[k].data_ptr() for k in ("W0", "b0", "Wp", "bh", "W8", "b8")])
+    lat = torch.zeros(3, dtype=torch.float64, device=pts.device)
+    lat[:2] = latent.reshape(-1)[:2]
+    rc = L.dss_igr_query_list(ctypes.byref(net), _lib.ptr(pts.contiguous()), None, _lib.ptr(lat), 3, None, int(n), 2, _lib.ptr(sdf), None,
+                              _lib.stream_ptr(pts.device))
+    _lib.check(rc, "dss_igr_query_list")
+    return sdf
+
+
 def weights_from_module(network):
     """(Ws, bs) of an IGR ``ImplicitNet``-like torch module: attributes ``lin0 .. lin8`` (torch.nn.Linear), as the
     external IGR repository defines it and the reference loads it (`utils.py:300-320`).  Only the bob_spot_setup shape

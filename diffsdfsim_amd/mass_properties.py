@@ -66,8 +66,13 @@ def mesh_inertia(verts, faces, mass, return_volume=False):
     voff = np.cumsum([0] + [len(v) for v in vs[:-1]]).astype(np.int32)
     foff = np.cumsum([0] + [len(f) for f in fs[:-1]]).astype(np.int32)
     nf = np.array([len(f) for f in fs], np.int32)
-    V = _dev(torch.cat([torch.as_tensor(v, dtype=torch.float64).detach().cpu() for v in vs]))
-    F = _dev(torch.cat([torch.as_tensor(f).detach().cpu().to(torch.int32) for f in fs]), torch.int32)
+    def pooled(xs, dtype):      # one pooled table on the device; tensors that are already there are not taken through the host
+        ts = [torch.as_tensor(x).detach().to(dtype) for x in xs]
+        if len(ts) == 1:
+            return _dev(ts[0], dtype)
+        dev = next((t.device for t in ts if t.is_cuda), None)
+        return _dev(torch.cat([t.to(dev) if dev is not None else t for t in ts]), dtype)
+    V, F = pooled(vs, torch.float64), pooled(fs, torch.int32)
     M = _dev(torch.tensor([float(m) for m in ms], dtype=torch.float64))
     d = V.device
     ti = lambda a: torch.as_tensor(a, dtype=torch.int32).to(d)

@@ -55,6 +55,17 @@ def _grid(res, device):
     return torch.stack(torch.meshgrid(g, g, g, indexing="ij"), dim=3).reshape(-1, 3)
 
 
+_GRIDS = {}
+GRID_EVENTS = None      # a list: _IgrMeshSDF.forward appends (start event, stop event, points) per network grid it evaluates
+
+
+def _grid_cached(res, device):
+    key = (int(res), str(device))
+    if key not in _GRIDS:
+        _GRIDS[key] = _grid(res, device)
+    return _GRIDS[key]
+
+
 class _PrimitiveMeshSDF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prm_unit, shape_type, res):
@@ -96,10 +107,17 @@ class _IgrMeshSDF(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, latent, packed_weights, res):
-        from .igr import igr_query
+        from .igr import igr_values
         dev = packed_weights["W0"].device
         lat = _dev(latent.detach())
-        sdf, _ = igr_query(_grid(res, dev), lat, packed_weights)
+        ev = GRID_EVENTS
+        if ev is not None:      # (bench.py: HIP events around the grid evaluation, the matrix-core share of a mesh build)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        sdf = igr_values(_grid_cached(res, dev), lat, packed_weights)      # values only: a quarter of the matrix work of value + gradient
+        if ev is not None:
+            b.record()
+            ev.append((a, b, res ** 3))
         verts, faces = marching_cubes(sdf.reshape(res, res, res), 0.0)
         verts = verts / (res - 1) * 2.0 - 1.0
         ctx.save_for_backward(verts, lat)

@@ -44,13 +44,44 @@ class _StepFn(torch.autograd.Function):
         ctx.index = world._n_nodes
         world._n_nodes += 1
         out_pose, out_vel = E.arr["pose"].clone(), E.arr["vel"].clone()
-        return out_pose, out_vel
+        if not getattr(world, "record_substeps", False):
+            ctx.nsubs = 0
+            return out_pose, out_vel
+        # The accepted sub-steps INSIDE this outer step (dt halving, time-of-contact events), as trajectory entries with a graph:
+        # entry k of scene s = the state after its k-th sub-step of this call, read from the tape slot that records the START of
+        # the next one; the last sub-step's entry is (out_pose, out_vel) itself.  sub_t = time at the start of each sub-step
+        # (the reference stamps its trajectory entries before `self.t += dt`, world.py:373-379).
+        cnt = ctx.nsub1 - nsub0                                           # [B] accepted sub-steps of this call
+        kmax = max(int(cnt.max().item()) - 1, 0)
+        ctx.nsubs = kmax
+        B = E.B
+        dev = out_pose.device
+        ar = torch.arange(B, device=dev)
+        ks = torch.arange(kmax + 1, device=dev)[:, None]                  # [kmax+1, 1]
+        slot = (nsub0.long()[None, :] + ks).clamp(max=max(int(E.W.max_sub) - 1, 0))
+        # (the time stamps are the world times the decide kernel recorded at the start of each sub-step -- the very sums
+        # `self.t += dt` forms in the reference: the experiments pair entries with the target entry NEAREST IN TIME, and a stamp
+        # midway between two target stamps is a tie that the last bit decides)
+        t_start = E.arr["tp_t"][slot, ar[None, :]] if int(E.W.max_sub) > 0 else world._t_before.to(dev)[None, :].expand(kmax + 1, B)
+        t_start = torch.where(ks < cnt.long()[None, :], t_start, world._t_before.to(dev)[None, :].expand(kmax + 1, B))
+        valid = ks[:kmax] < (cnt.long() - 1)[None, :]                     # intermediate entries (not the last sub-step)
+        nxt = (nsub0.long()[None, :] + ks[:kmax] + 1).clamp(max=max(int(E.W.max_sub) - 1, 0))
+        if kmax > 0:
+            sub_pose = E.arr["tp_pose"][nxt, ar[None, :]].clone()
+            sub_vel = E.arr["tp_vel"][nxt, ar[None, :]].clone()
+        else:
+            sub_pose = out_pose.new_zeros((0,) + tuple(out_pose.shape)); sub_vel = out_vel.new_zeros((0,) + tuple(out_vel.shape))
+        last_t = torch.gather(t_start, 0, (cnt.long() - 1).clamp(min=0)[None, :])[0]      # start time of the last sub-step
+        t_sub = t_start[:kmax].clone()
+        ctx.mark_non_differentiable(valid, t_sub, last_t)
+        return out_pose, out_vel, sub_pose, sub_vel, t_sub, valid, last_t
 
     @staticmethod
-    def backward(ctx, g_pose, g_vel):
+    def backward(ctx, g_pose, g_vel, g_sub_pose=None, g_sub_vel=None, *_unused):
         w = ctx.world
         E = w.engine
         adj = E._adjoint()
+        ctx_saved = None
         if ctx.index == w._n_nodes - 1 or w._bw_next != ctx.index:   # newest node: start a fresh reverse sweep
             adj["a_geom"].zero_()
             adj["a_last_dt"].zero_()
@@ -60,6 +91,20 @@ class _StepFn(torch.autograd.Function):
             if bool((E.arr["nsub"] < ctx.nsub1).any()):
                 raise RuntimeError("backward through a step whose tape slots were released by undo_step()")
             adj["cur_slot"].copy_(ctx.nsub1 - 1)
+        else:
+            # A scene for which this node is OUT OF THE CHAIN: its step was undone (undo_step) and redone by the next node, yet an
+            # output of it is still part of the loss -- the reference's trajectory keeps the first entry of an undone step
+            # (world.py:114-116), with its graph.  The sweep of such a scene has already passed these tape slots (the redo wrote
+            # the same values into them); it goes over them once more for this node's own incoming gradient, with the contact /
+            # time-of-contact adjoints the later steps left for the earlier ones set aside and added back afterwards.
+            off = (adj["cur_slot"] != ctx.nsub1 - 1) & (ctx.nsub1 > ctx.nsub0)
+            if bool(off.any()):
+                ctx_saved = (off, adj["a_geom"][off].clone(), adj["a_last_dt"][off].clone())
+                adj["a_geom"][off] = 0.0
+                adj["a_last_dt"][off] = 0.0
+                adj["cur_slot"][off] = (ctx.nsub1 - 1)[off]
+            else:
+                ctx_saved = None
         w._bw_next = ctx.index - 1
         for k in ("g_mass", "g_inertia", "g_rest", "g_fric", "g_fext", "g_prm", "g_verts"):
             adj[k].zero_()
@@ -68,7 +113,26 @@ class _StepFn(torch.autograd.Function):
         adj["a_vel"].copy_(g_vel)
         first = ctx.index == 0
         adj["lo_slot"].copy_(ctx.nsub0 - (1 if first else 0))   # slot -1: contacts found at construction
-        E.backward_sweep(ctx.att + (1 if first else 0))
+        if ctx.nsubs > 0 and g_sub_pose is not None:
+            # adjoints of the intermediate entries join the sweep where it passes their state: after slot j has been undone
+            # a_pose / a_vel belong to the state at the START of sub-step j = entry (j - 1 - nsub0) of this call
+            n0 = ctx.nsub0.long()
+            ar = torch.arange(E.B, device=adj["a_pose"].device)
+            for _ in range(ctx.att + (1 if first else 0)):
+                before = adj["cur_slot"].clone()
+                E.backward_sweep(1)
+                cur = adj["cur_slot"].long()
+                k = cur - n0                                                 # entry whose state the adjoint now describes
+                hit = (adj["cur_slot"] != before) & (k >= 0) & (k < ctx.nsubs)
+                kk = k.clamp(0, ctx.nsubs - 1)
+                adj["a_pose"] += torch.where(hit[:, None, None], g_sub_pose[kk, ar], torch.zeros_like(adj["a_pose"]))
+                adj["a_vel"] += torch.where(hit[:, None, None], g_sub_vel[kk, ar], torch.zeros_like(adj["a_vel"]))
+        else:
+            E.backward_sweep(ctx.att + (1 if first else 0))
+        if ctx_saved is not None:
+            off, ag, al = ctx_saved
+            adj["a_geom"][off] += ag
+            adj["a_last_dt"][off] += al
         return (None, None, adj["a_pose"].clone(), adj["a_vel"].clone(), adj["g_mass"].clone(),
                 adj["g_inertia"].reshape(E.B, E.nb, 3, 3).clone(), adj["g_rest"].clone(), adj["g_fric"].clone(),
                 adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None, None)
@@ -128,10 +192,16 @@ class BatchWorld3D:
                 hit = (x, x._version, x.to(self.device))
                 dev_cache[name] = hit
             return hit[2]
-        self.pose, self.vel = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
-                                            to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
-                                            to("fext", P["fext"]), to("shape_prm", P["shape_prm"]),
-                                            to("verts", P["verts"]) if P.get("verts") is not None else None, mask)
+        if getattr(self, "record_substeps", False):
+            self._t_before = torch.as_tensor(E.get("t").copy())
+        outs = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
+                             to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
+                             to("fext", P["fext"]), to("shape_prm", P["shape_prm"]),
+                             to("verts", P["verts"]) if P.get("verts") is not None else None, mask)
+        self.pose, self.vel = outs[0], outs[1]
+        # (record_substeps: the entries of the sub-steps inside this call -- poses / velocities [K, B, ...] with their graph, start
+        # times [K, B], validity [K, B] -- and the start time of the last sub-step, whose entry is (self.pose, self.vel))
+        self.substeps = dict(pose=outs[2], vel=outs[3], t=outs[4], valid=outs[5], last_t=outs[6]) if len(outs) > 2 else None
         up = self.__dict__.setdefault("_uploaded", {})
         up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
         had = self.engine.get("had_contacts") > 0
@@ -303,17 +373,16 @@ class World3D(BatchWorld3D):
         n1 = int(E.get("nsub")[0])
         t = t0
         if n1 - n0 > 1 and n1 <= int(E.W.max_sub):
-            tp, tv, tdt = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_dt")
+            tp, tv, tt = E.get("tp_pose"), E.get("tp_vel"), E.get("tp_t")
             tnc, tb, tg = E.get("tp_nc"), E.get("tp_body"), E.get("tp_geom")
             for j in range(n0, n1 - 1):          # the state after sub-step j = the start of sub-step j + 1
                 cs = []
                 for c in range(int(tnc[j + 1, 0])):
                     g_, b_ = tg[j + 1, 0], tb[j + 1, 0]
-                    tt = lambda a: torch.tensor(a.copy())
-                    cs.append(((tt(g_[0:3, c]), tt(g_[3:6, c]), tt(g_[6:9, c]), tt(g_[9, c])), int(b_[0, c]), int(b_[1, c])))
-                self.trajectory.append((t, torch.tensor(tp[j + 1, 0].reshape(-1)), torch.tensor(tv[j + 1, 0].reshape(-1)), cs, None))
-                t += float(tdt[j, 0])
-            t = self._t - float(tdt[n1 - 1, 0])      # start of the last sub-step
+                    tt_ = lambda a: torch.tensor(a.copy())
+                    cs.append(((tt_(g_[0:3, c]), tt_(g_[3:6, c]), tt_(g_[6:9, c]), tt_(g_[9, c])), int(b_[0, c]), int(b_[1, c])))
+                self.trajectory.append((float(tt[j, 0]), torch.tensor(tp[j + 1, 0].reshape(-1)), torch.tensor(tv[j + 1, 0].reshape(-1)), cs, None))
+            t = float(tt[n1 - 1, 0])             # start of the last sub-step (the kernel's own `t`, the sums `self.t += dt` forms)
         self.trajectory.append((t, self.pose[0].reshape(-1), self.vel[0].reshape(-1), self.contacts, None))
         return had
 

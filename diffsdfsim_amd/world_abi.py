@@ -40,7 +40,7 @@ FIELDS = [
     ("max_sub", "i"),
     ("tp_pose", "pd"), ("tp_vel", "pd"), ("tp_dt", "pd"), ("tp_x", "pd"), ("tp_lam", "pd"), ("tp_slack", "pd"),
     ("tp_nu", "pd"), ("tp_abc", "pd"), ("tp_geom", "pd"),
-    ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"), ("tp_flags", "pi"),
+    ("tp_nc", "pi"), ("tp_body", "pi"), ("tp_face", "pi"), ("tp_flags", "pi"), ("tp_t", "pd"),
     ("ev_lcp_start", "ev"), ("ev_lcp_stop", "ev"), ("ev_np_start", "ev"), ("ev_np_stop", "ev"), ("dbg_stamps", "ev"),
     # neural SDF bodies: DssIgrNet (six pointers), capacities, the round-based narrow phase's item state and query lists
     ("igr_W0", "pd"), ("igr_b0", "pd"), ("igr_Wp", "pd"), ("igr_bh", "pd"), ("igr_W8", "pd"), ("igr_b8", "pd"),
@@ -105,7 +105,7 @@ def array_shapes(B, nb, neq, maxc, fd, max_cand, max_pc, max_sub, nmesh, NV, NF,
             "tp_pose": (max_sub, B, nb, 7), "tp_vel": (max_sub, B, nb, 6), "tp_dt": (max_sub, B), "tp_x": (max_sub, B, nz),
             "tp_lam": (max_sub, B, NR, maxc), "tp_slack": (max_sub, B, NR, maxc), "tp_nu": (max_sub, B, max(neq, 1)),
             "tp_abc": (max_sub, B, 3, maxc), "tp_geom": (max_sub, B, 10, maxc),
-            "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc), "tp_flags": (max_sub, B),
+            "tp_nc": (max_sub, B), "tp_body": (max_sub, B, 2, maxc), "tp_face": (max_sub, B, maxc), "tp_flags": (max_sub, B), "tp_t": (max_sub, B),
         })
     return s
 

@@ -203,6 +203,8 @@ typedef struct DssWorld {
     double *tp_pose, *tp_vel, *tp_dt, *tp_x, *tp_lam, *tp_slack, *tp_nu, *tp_abc, *tp_geom;
     int *tp_nc, *tp_body, *tp_face;
     int *tp_flags;   /* bit 0: the sub-step ended with a time-of-contact event, bit 1: its dt_ used last_dt (world.py:253-257) */
+    double *tp_t;    /* [max_sub][B] world time at the START of the sub-step: the stamp the reference gives the trajectory entry
+                        it appends for it (world.py:373-379, before `self.t += dt`); may be NULL */
     /* optional hipEvent_t pair recorded around the LCP launch of dss_step_attempt (bench roofline) */
     void *ev_lcp_start, *ev_lcp_stop;
     void *ev_np_start, *ev_np_stop;   /* same, around the contact-detection launches */
