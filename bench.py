@@ -70,10 +70,10 @@ def lib_hash():
 
 
 def load_pmc(config):
-    """Counter totals per launch from rocprofv3 --pmc passes of this same command (tools/pmc.sh -> profiles/r2_pmc_config<N>.json),
+    """Counter totals per launch from rocprofv3 --pmc passes of this same command (tools/pmc.sh -> profiles/r3_pmc_config<N>.json),
     valid only for the library build they were taken on (the file carries its hash)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_config%d.json" % config)))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_config%d.json" % config)))
     except Exception:
         return {}, "no PMC file for this config"
     if d.get("lib_sha256") != lib_hash():

@@ -246,12 +246,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     auto test_face = [&](int f, double pqr[3][3]) -> int {
         return cull_face(m_fcent + (size_t)(A.foff + f) * 3) ? full_face(f, pqr) : 0;
     };
-#if defined(DSS_NP_SCAN_STAMPS)
-#define SSTAMP(i) STAMP(i)
-#else
-#define SSTAMP(i)
-#endif
-    SSTAMP(1);
     if (G::BT == 64) {
         // one wavefront: (a) centroid pre-test of the runs that can hold a candidate, four independent loads in
         // flight, survivors packed in ascending order into LDS; (b) the full test on dense lanes.
@@ -283,7 +277,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         }
         if (npass > G::HCAP) return 1;   // more runs in reach than the wavefront's list holds: a workgroup takes the item
         G::sync();
-        SSTAMP(2);
         int *surv = reinterpret_cast<int *>(S.hp);
         constexpr int SCAP = (int)(sizeof(S.hp) / sizeof(int)) - 4 * 64;
         int nsurv = 0;
@@ -328,9 +321,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
             }
             if (nsurv > SCAP) flush();
         }
-        SSTAMP(3);
         if (nsurv > 0) flush();
-        SSTAMP(4);
         if (ncand > MC) { over |= 1; ncand = MC; }
         if (tid == 0) { W.pc_stats[((size_t)sc * np + dp) * 2] = npass; W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = ncand; }
         G::sync();
@@ -401,13 +392,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     }
     if (ncand == 0) { if (tid == 0) *pc_count = 0; return 0; }
     G::sync();
-#if !defined(DSS_NP_SCAN_STAMPS)
     STAMP(1);
-#endif
-#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 1
-    if (tid == 0) *pc_count = 0;
-    return 0;
-#endif
 
     // ---- 2. Frank-Wolfe (contacts.py:57-82) -----------------------------------------------------
     // The first candidate of every thread lives in registers for the whole loop (typical pairs have fewer
@@ -487,9 +472,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         if (nmov > G::HCAP) { if (G::BT == 64) return 1; over |= 2; nmov = G::HCAP; }
         G::sync();
     }
-#if defined(DSS_NP_STAT_NMOV)
-    if (tid == 0) W.pc_stats[((size_t)sc * np + dp) * 2 + 1] = nmov;      // (experiment: movers instead of candidates)
-#endif
     if (G::BT == 64 && nmov > 0 && nmov <= 16) {
         // Few movers, one wavefront: the loop is a serial chain (evaluate -> pick a vertex -> move -> evaluate ...)
         // on a handful of lanes.  The step size of iteration k is known in advance (2 / (k + 2), float32), so the
@@ -567,10 +549,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     G::sync();
 
     STAMP(2);
-#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 2
-    if (tid == 0) *pc_count = 0;
-    return 0;
-#endif
     // ---- 3. pull onto body a's surface, keep phi_b <= eps (contacts.py:84-94) ...
     double qrel[4];
     {
@@ -624,10 +602,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
     G::sync();
 
     STAMP(3);
-#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 3
-    if (tid == 0) *pc_count = 0;
-    return 0;
-#endif
     if (G::any(bad)) {
         if (tid == 0) { W.invalid[sc] = 1; *pc_count = 0; }
         // attempts that will be accepted all the same (decide_kernel: strict_no_penetration=False, dt < dt / 2^10) keep this
@@ -637,10 +611,6 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
         return 0;
     }
 
-#if defined(DSS_NP_EXP_STOP) && DSS_NP_EXP_STOP == 4
-    if (tid == 0) *pc_count = 0;
-    return 0;
-#endif
 #define NP_PRESTATE 1
 #include "np_filter_emit.inc"
 #undef NP_PRESTATE
@@ -654,9 +624,7 @@ template <class G> __device__ int narrow_pair(const DssWorld &W, ScratchT<G> &S,
 // wavefronts on one item), then its wavefronts split up and walk the wave list independently.  A wave item that
 // outgrows the wave-sized scratch is appended to the deferred list, which a second launch works off block-wise.
 union NpScratch {
-#if !defined(DSS_NP_EXP_STOP)
     ScratchT<BlockGroup> blk;
-#endif
     ScratchT<WaveGroup> wav[BlockGroup::NW];
 };
 template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) narrowphase_kernel(DssWorld W_arg)
@@ -665,7 +633,6 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
     __shared__ NpScratch S;
     __shared__ int s_item;
     const int cap = W.B * npairs_of(W.nb), seg = DEFERRED ? 2 : 0;
-#if !defined(DSS_NP_EXP_STOP)
     {
         const int n = W.n_pairs[DEFERRED ? 4 : 0];
         const int *list = W.pair_list + (size_t)seg * cap;
@@ -678,7 +645,6 @@ template <bool DEFERRED> __global__ void __launch_bounds__(NT, DSS_NP_WAVES) nar
             narrow_pair<BlockGroup>(W, S.blk, list[it], (int)blockIdx.x * BlockGroup::NW);
         }
     }
-#endif
     if (DEFERRED) return;
     __syncthreads();   // nobody still reads the block scratch
     const int n = W.n_pairs[1], lane = threadIdx.x & 63;

@@ -14,7 +14,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 E = BatchEngine(scenes.box_stack(B, nbox=7, seed=1), maxc=128, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
 st = torch.zeros(B * 16, dtype=torch.int64, device="cuda")
 E.be.lib.dss_diag_set_lcp_stamps(ctypes.c_void_p(st.data_ptr()), E.be.stream())
-E.step(); torch.cuda.synchronize()
+try:
+    E.step()
+except RuntimeError as e:
+    print("(step raised:", str(e)[:60], ")")
+torch.cuda.synchronize()
 d = st.cpu().numpy().reshape(B, 16) / 100.0
 names = ["pre", "P1 resid+Cmat pass", "gather2", "resid/best", "C to LDS", "assemble_K", "-", "factor+solve aff", "P4 pass", "sigma+P5 pass", "gather1+solve cor", "P6 pass", "update"]
 tot = d.sum(1).mean()

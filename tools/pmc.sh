@@ -2,8 +2,8 @@
 # Dev aid (GPU box): per-kernel counters of the bench command from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
 # SEPARATE passes, MI355X guide, HBM section; fp64 instruction counts; VALU / MFMA busy cycles), plus a kernel-stats pass of
 # the same command.  Usage: tools/pmc.sh <config> <steps> [batch]
-#   -> gpurun_out/r2_pmc_config<N>.json (stamped with the library's hash: bench.py reports its numbers only for that build)
-#      gpurun_out/r2_kernel_stats_config<N>.csv        (copy both into profiles/ to have them judged)
+#   -> gpurun_out/r3_pmc_config<N>.json (stamped with the library's hash: bench.py reports its numbers only for that build)
+#      gpurun_out/r3_kernel_stats_config<N>.csv        (copy both into profiles/ to have them judged)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${1:-3}
 STEPS=${2:-5}
@@ -54,10 +54,10 @@ for k, e in kern.items():
         e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (e["GRBM_GUI_ACTIVE_avg"] / 8.0 * 1024.0)
 lib = "diffsdfsim_amd/csrc/libdiffsdfsim_hip.so"
 res = {"config": int(cfg), "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16], "kernels": kern}
-json.dump(res, open("gpurun_out/r2_pmc_config%s.json" % cfg, "w"), indent=1)
+json.dump(res, open("gpurun_out/r3_pmc_config%s.json" % cfg, "w"), indent=1)
 ks = glob.glob("%s/kstats/*/*kernel_stats.csv" % out_dir)
 if ks:
-    shutil.copy(ks[0], "gpurun_out/r2_kernel_stats_config%s.csv" % cfg)
+    shutil.copy(ks[0], "gpurun_out/r3_kernel_stats_config%s.csv" % cfg)
 for k, v in kern.items():
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
 PY
