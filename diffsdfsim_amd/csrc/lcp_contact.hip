@@ -171,17 +171,17 @@ struct Lds {
     double *pl;     // [nz] linear term
     int *piv;       // [n]
     int *cb;        // [2][maxc] body ids (LDS copy)
-    int *chunk;     // [maxc] first contact of every piece of at most CHUNK consecutive contacts of one (body1, body2) run
+    int *chunk;     // [maxc] first contact of every piece of at most chunk_len(nc) consecutive contacts of one (body1, body2) run
     int nchunks;
     int n, kn, lda, nz, neq, nb, maxc, nc;
     double *kf;     // global: [n][64] factored rows parked between the solves of an iteration (register path)
     const double *Ag;   // global equality rows [neq][nz]
 };
 
-#if !defined(DSS_LCP_CHUNK)
-#define DSS_LCP_CHUNK 4
-#endif
-constexpr int CHUNK = DSS_LCP_CHUNK;     // contacts per piece of a run: one lane sums the P C P^T terms of one piece (assemble_K)
+// contacts per piece of a run (one lane sums the P C P^T terms of one piece, assemble_K): with many contacts longer pieces keep
+// the number of lanes that meet at an LDS address down (84 contacts: 4 per piece measured best, 0.704 / 0.672 / 0.722 ms per
+// launch for 8 / 4 / 2); with few contacts every lane's chain should be as short as possible (config 2: <= 8 contacts)
+__device__ inline int chunk_len(int nc) { return nc > 48 ? 4 : (nc > 24 ? 2 : 1); }
 // sizes with a register-resident factor/solve: only H = Q + sum P C P^T is assembled in LDS, the equality rows join
 // in registers and the factored rows are parked in the (L2-resident) workspace between the two solves of an iteration
 __host__ __device__ inline bool reg_path(int n) { return n == 54 || n == 18; }
@@ -219,13 +219,14 @@ __device__ inline void carve_lds(Lds &L, double *base, int nb, int neq, int maxc
 }
 
 // Pieces for assemble_K: detection emits contacts pair by pair, so the contacts of one (body1, body2) form a run; a run is cut
-// into pieces of at most CHUNK contacts.  Contact c opens a piece if it opens a run or sits a multiple of CHUNK behind the
+// into pieces of at most chunk_len(nc) contacts.  Contact c opens a piece if it opens a run or sits a multiple of that behind the
 // start of its run (inclusive prefix maximum of the run starts); ordered compaction of the openers by ballot prefix sums.
 // Needs the body ids in L.cb.
 __device__ void build_chunks(Lds &L, int nc)
 {
     const int lane = lane_id();
     const int *cbody = L.cb;
+    const int CHUNK = chunk_len(nc);
     int nch = 0, carry = -1;
     for (int base = 0; base < nc; base += WAVE) {
         const int c = base + lane;
@@ -317,7 +318,7 @@ template <int NP> __device__ void gather(const Lds &L, double *out0, double *out
 //
 // The contact terms.  P_c = [X(p1); I; -X(p2); -I] (12 x 3), so the 12 x 12 block of a contact is made of
 //   rows of  A C  with A in {X(p1), I, X(p2), I}   times   {X(p1)^T, I, X(p2)^T, I}:   (y X(p)^T) = p x y  for a row y.
-// Lanes = PIECES of at most CHUNK consecutive contacts of one (body1, body2) run: a lane forms the terms of its own contacts
+// Lanes = PIECES of at most chunk_len(nc) consecutive contacts of one (body1, body2) run: a lane forms the terms of its own contacts
 // and sums them in registers, one 3-row band of the 12 x 12 block at a time (27 running sums), without a word to any other
 // lane; the bands are then added into K with LDS atomics (one wavefront, one instruction stream: lanes that meet at an
 // address are served in a fixed order, program order settles the rest -- the sum is reproducible run to run).  Before, 48
