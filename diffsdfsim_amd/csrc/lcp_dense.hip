@@ -14,6 +14,7 @@
 // walked with lane = column so every global access is a coalesced 512-B row segment.
 #include "dss_device.h"
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/diffsdfsim_hip.h"
 #include "wave_utils.h"
@@ -555,6 +556,17 @@ lcp_dense_backward_kernel(const double *Q, const double *G, const double *A, con
 
 }  // namespace
 
+namespace dss {      // lcp_dense_group.hip: eight lanes per system, for nz, nineq, neq <= 8
+bool lcp_dense_group_fits(int nz, int nineq, int neq);
+int launch_lcp_dense_group_forward(const double *Q, const double *p, const double *G, const double *h, const double *A, const double *b,
+                                   const double *F, int B, int nz, int nineq, int neq, double eps, int not_improved_lim, int max_iter,
+                                   int check_spd, double *zhat, double *lam, double *slack, double *nu, int *iters, int *status,
+                                   hipStream_t stream);
+int launch_lcp_dense_group_backward(const double *Q, const double *G, const double *A, const double *F, int B, int nz, int nineq, int neq,
+                                    const double *zhat, const double *lam, const double *slack, const double *nu, const double *dl_dz,
+                                    double *dQ, double *dp, double *dG, double *dh, double *dA, double *db, double *dF, hipStream_t stream);
+}
+
 extern "C" {
 
 int dss_abi_version(void) { return DSS_ABI_VERSION; }
@@ -575,6 +587,10 @@ int dss_lcp_dense_forward(const double *Q, const double *p, const double *G, con
     if (!Q || !p || !G || !h || !F || !zhat || !lam || !slack || !iters || !status || !workspace) return DSS_E_BADARG;
     if (neq > 0 && (!A || !b || !nu)) return DSS_E_BADARG;
     if (workspace_bytes < dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)) return DSS_E_WORKSPACE;
+    // tiny systems: eight lanes per system, eight systems per wavefront, everything in registers (no workspace touched)
+    if (dss::lcp_dense_group_fits(nz, nineq, neq) && !getenv("DSS_LCP_DENSE_WAVE"))
+        return dss::launch_lcp_dense_group_forward(Q, p, G, h, A, b, F, B, nz, nineq, neq, eps, not_improved_lim, max_iter, check_spd, zhat,
+                                                   lam, slack, nu, iters, status, (hipStream_t)stream);
     size_t lds = lds_bytes(nz, nineq, neq);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     const int in_lds = lds + ws_bytes_per_system(nz, nineq, neq) <= WS_LDS_BUDGET;
@@ -595,6 +611,9 @@ int dss_lcp_dense_backward(const double *Q, const double *G, const double *A, co
     if (!Q || !G || !F || !zhat || !lam || !slack || !dl_dz || !dQ || !dp || !dG || !dh || !dF || !workspace) return DSS_E_BADARG;
     if (neq > 0 && (!A || !nu || !dA || !db)) return DSS_E_BADARG;
     if (workspace_bytes < dss_lcp_dense_workspace_bytes(B, nz, nineq, neq)) return DSS_E_WORKSPACE;
+    if (dss::lcp_dense_group_fits(nz, nineq, neq) && !getenv("DSS_LCP_DENSE_WAVE"))
+        return dss::launch_lcp_dense_group_backward(Q, G, A, F, B, nz, nineq, neq, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, dF,
+                                                    (hipStream_t)stream);
     size_t lds = lds_bytes(nz, nineq, neq);
     if (lds > 64 * 1024) return DSS_E_UNSUPPORTED;
     const int in_lds = lds + ws_bytes_per_system(nz, nineq, neq) <= WS_LDS_BUDGET;

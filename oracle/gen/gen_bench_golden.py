@@ -12,8 +12,9 @@ The floor's mesh is NOT stored (20 x 1 x 20: 176 000 faces), its three grid axes
 `diffsdfsim_amd.meshes.box_mesh(dims, grid_axes=...)` rebuilds the reference's `_custom_create_mesh` output bit for bit.  (Without the
 axes the two differ in the last bit of interior grid coordinates: torch.linspace vs numpy.)
 
-Output: tests/golden/bench_stack_s<k>.npz (k = 0..7, >= 10 outer steps) and tests/golden/bench_sphere_s<k>.npz (k = 0..3,
-200 outer steps with time-of-contact differentiation on).
+Output: tests/golden/bench_stack_s<k>.npz (k = 0..7, >= 10 outer steps), tests/golden/bench_sphere_s<k>.npz (k = 0..3,
+200 outer steps with time-of-contact differentiation on) and -- `stack200` -- tests/golden/bench_stack_s1_200steps.npz (scene 1 over
+BASELINE's full horizon of 200 steps).
 """
 import os
 import sys
@@ -100,6 +101,10 @@ def main():
         assert np.array_equal(full["pose"][:8], spec["pose"]), "scene k must not depend on the batch size"
         for s in range(8):
             G.run("bench_stack_s%d" % s, lambda s=s: reference_bodies(spec, s), nsteps=10, store_mesh=False, extra=floor_axes)
+    if "stack200" in which:
+        # the BASELINE horizon: scene 1 of the benchmark batch for the full 200 steps (the stack settles and rests)
+        spec = build_scenes.box_stack(8, seed=BENCH_SEED)
+        G.run("bench_stack_s1_200steps", lambda: reference_bodies(spec, 1), nsteps=200, store_mesh=False, extra=floor_axes)
     if "sphere" in which:
         spec = build_scenes.sphere_drop(4, seed=BENCH_SEED)
         for s in range(4):

@@ -111,3 +111,24 @@ def test_config1_reference_cpu_case_through_lcpfunction():
         want = O.backward(c["Q"], c["G"], c["A"], c["F"], c["z"], c["lam"], c["slack"], c["nu"], c["dl"])
         for t, w in zip(ops, want):
             assert rel(t.grad.cpu().numpy(), w) < 1e-7
+
+
+@pytest.mark.parametrize("nB,nz,nineq,neq", [(1003, 6, 4, 3), (4099, 6, 8, 3), (517, 3, 4, 0), (260, 8, 8, 5)])
+def test_eight_lanes_per_system_kernel_matches_oracle(nB, nz, nineq, neq):
+    """csrc/lcp_dense_group.hip (nz, nineq, neq <= 8: eight systems per wavefront) on batches that do not fill their last
+    wavefront: iterates, iteration counts and status against the C oracle, the implicit backward too."""
+    from diffsdfsim_amd.lcp.lcp import lcp_dense_backward, lcp_dense_forward
+    from oracle import lcp_oracle as O
+    Q, p, G, h, A, b, F = random_lcp(5 + nz + nineq, nB, nz, nineq, neq)
+    out = lcp_dense_forward(*(T(x) for x in (Q, p, G, h, A, b, F)), 1e-12, 3, 20, True)
+    z, lam, s, nu, it, st = [o.cpu().numpy() for o in out]
+    zo, lo, so, nuo, ito, sto = O.forward(Q, p, G, h, A, b, F)
+    assert (st == sto).all() and (it == ito).mean() > 0.995, ((it != ito).sum(), nB)      # (a residual tie may move one stop by an iteration)
+    same = it == ito
+    assert rel(z[same], zo[same]) < 1e-9 and rel(s[same], so[same]) < 1e-6
+    dl = np.random.default_rng(3).standard_normal((nB, nz))
+    got = lcp_dense_backward(*(T(x) for x in (Q, G, A, F, zo, lo, so, nuo if neq else np.zeros((nB, 0)), dl)))
+    ref = O.backward(Q, G, A, F, zo, lo, so, nuo, dl)
+    for name, g_, want in zip("QpGhAbF", got, ref):
+        if want.size and g_ is not None:
+            assert rel(g_.cpu().numpy(), want) < 1e-7, name
