@@ -28,133 +28,196 @@ using namespace dss;
 constexpr int GS = 8;      // lanes per system = rows / columns of the register tiles
 
 __device__ __forceinline__ int grp_lane() { return threadIdx.x & (GS - 1); }
+// value of lane `src` of the own group, src a run-time number (the pivot lane of a pivoted elimination): ds_bpermute
 __device__ __forceinline__ double gsh(double x, int src) { return __shfl(x, (threadIdx.x & (WAVE - GS)) | src, WAVE); }
-__device__ __forceinline__ int gshi(int x, int src) { return __shfl(x, (threadIdx.x & (WAVE - GS)) | src, WAVE); }
+
+// Cross-lane traffic with COMPILE-TIME partners runs on the DPP path of the vector ALU (a few cycles) instead of through the
+// LDS crossbar (ds_bpermute / ds_swizzle: > 100 cycles each, and the solves are chains of them):
+//   quad_perm for partners inside a quad, row_half_mirror (lane i <-> 7 - i of every 8) to cross between the two quads.
+#if defined(DSS_EMU)
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
+{
+    const int l = threadIdx.x & 63, q = l & ~3, i = l & 3;
+    const int src = CTRL == 0x141 ? (l & ~7) | (7 - (l & 7)) : q | ((CTRL >> (2 * i)) & 3);
+    return __shfl(x, src, WAVE);
+}
+template <int CTRL> __device__ __forceinline__ int dpp_movi(int x)
+{
+    const int l = threadIdx.x & 63, q = l & ~3, i = l & 3;
+    const int src = CTRL == 0x141 ? (l & ~7) | (7 - (l & 7)) : q | ((CTRL >> (2 * i)) & 3);
+    return __shfl(x, src, WAVE);
+}
+#else
+template <int CTRL> __device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
+{
+    return __hiloint2double(dpp_movi<CTRL>(__double2hiint(x)), dpp_movi<CTRL>(__double2loint(x)));
+}
+#endif
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;     // quad_perm [1,0,3,2], [2,3,0,1]; row_half_mirror
+
+// broadcast of lane J of every group of eight, J a compile-time constant: within J's quad by quad_perm, to the other quad through
+// the half mirror (2 DPP moves + a select per 32-bit half)
+template <int J> __device__ __forceinline__ double gbc(double x)
+{
+    const double inq = dpp_mov<(J & 3) * 0x55>(x);          // every lane: element (J & 3) of its own quad
+    const double oth = dpp_mov<DPP_HALF_MIRROR>(inq);       // ... of the other quad of its group
+    return ((threadIdx.x >> 2) & 1) == (J >> 2) ? inq : oth;
+}
 __device__ __forceinline__ double gsum(double v)
 {
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ double gmin(double v)
 {
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
+    v = fmin(v, dpp_mov<DPP_XOR1>(v)); v = fmin(v, dpp_mov<DPP_XOR2>(v)); v = fmin(v, dpp_mov<DPP_HALF_MIRROR>(v));
     return v;
 }
 __device__ __forceinline__ double gmax(double v)
 {
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    v = fmax(v, dpp_mov<DPP_XOR1>(v)); v = fmax(v, dpp_mov<DPP_XOR2>(v)); v = fmax(v, dpp_mov<DPP_HALF_MIRROR>(v));
     return v;
 }
+// arg-max over the group, lowest lane on ties (LAPACK idamax)
+template <int CTRL> __device__ __forceinline__ void argmax_step(double &v, int &idx)
+{
+    const double ov = dpp_mov<CTRL>(v);
+    const int oi = dpp_movi<CTRL>(idx);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
 
-// A row-distributed n x n matrix factored in place with partial pivoting; rows never move.
-//   a[k] of a lane that was not yet pivot at step k = multiplier l_{r,k};  a[j >= k] of the step-k pivot lane = U_{k,j}.
+// A row-distributed n x n matrix factored in place; rows never move.
+//   PIV = true: partial pivoting by an implicit permutation -- the lane that wins the column's arg-max becomes the pivot of the
+//     step and drops out; its row is broadcast with ds_bpermute (the source lane is a run-time number).  For T = R + diag(s/z),
+//     which is not symmetric (F is not), as the reference factors it on the CPU (batch.py:33, 500-517).
+//   PIV = false: natural order, every partner a compile-time lane (DPP).  For Q and A Q^-1 A^T, which are symmetric positive
+//     definite: elimination without pivoting is backward stable there.
+//   a[k] of a lane that was not yet pivot at step k = multiplier l_{r,k};  the step-k pivot lane holds U_{k,j} in a[j > k] and
+//   1 / U_{k,k} in a[k] (one division per step of the factorisation instead of one per step of every solve).
 struct GLU {
     double a[GS];
-    int ord;          // the step at which this lane's row was the pivot (n..: never, i.e. r >= n)
+    int ord;          // the step at which this lane's row was the pivot (GS: never, i.e. r >= n)
     unsigned piv;     // pivot lane of step k in bits [3k, 3k+3)  (the same in every lane of the group)
 };
 
-__device__ inline int glu_factor(GLU &M, int n)
+template <bool PIV, int K> __device__ __forceinline__ void glu_factor_step(GLU &M, int n, int &info)
 {
+    if (K >= n) return;
     const int r = grp_lane();
+    int p = K;
+    double pr[GS];
+    bool ok = true;
+    if (PIV) {
+        double v = (M.ord == GS && r < n) ? fabs(M.a[K]) : -1.0;
+        int idx = r;
+        argmax_step<DPP_XOR1>(v, idx); argmax_step<DPP_XOR2>(v, idx); argmax_step<DPP_HALF_MIRROR>(v, idx);
+        p = idx;
+        M.piv |= (unsigned)p << (3 * K);
+        ok = v > 0.0;
+#pragma unroll
+        for (int j = K; j < GS; ++j) pr[j] = gsh(M.a[j], p);
+    } else {
+#pragma unroll
+        for (int j = K; j < GS; ++j) pr[j] = gbc<K>(M.a[j]);
+        ok = pr[K] != 0.0;
+    }
+    if (!ok && !info) info = K + 1;
+    const double inv = 1.0 / pr[K];
+    const bool is_pivot = r == p;
+    const bool below = PIV ? (M.ord == GS && r < n && !is_pivot) : (r > K && r < n);
+    if (is_pivot) { M.ord = K; M.a[K] = inv; }
+    else if (below && ok) {
+        const double l = M.a[K] * inv;
+        M.a[K] = l;
+#pragma unroll
+        for (int j = K + 1; j < GS; ++j) M.a[j] -= l * pr[j];
+    }
+}
+template <bool PIV> __device__ __forceinline__ int glu_factor(GLU &M, int n)
+{
     M.ord = GS; M.piv = 0u;
     int info = 0;
-#pragma unroll
-    for (int k = 0; k < GS; ++k) {
-        if (k >= n) break;
-        double v = (M.ord == GS && r < n) ? fabs(M.a[k]) : -1.0;
-        int idx = r;
-#pragma unroll
-        for (int o = GS / 2; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(v, o, WAVE);
-            const int oi = __shfl_xor(idx, o, WAVE);
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-        const int p = idx;
-        M.piv |= (unsigned)p << (3 * k);
-        if (!(v > 0.0) && !info) info = k + 1;
-        double pr[GS];
-#pragma unroll
-        for (int j = k; j < GS; ++j) pr[j] = gsh(M.a[j], p);
-        if (r == p) M.ord = k;
-        else if (M.ord == GS && r < n && v > 0.0) {
-            const double l = M.a[k] / pr[k];
-            M.a[k] = l;
-#pragma unroll
-            for (int j = k + 1; j < GS; ++j) M.a[j] -= l * pr[j];
-        }
-    }
+    glu_factor_step<PIV, 0>(M, n, info); glu_factor_step<PIV, 1>(M, n, info); glu_factor_step<PIV, 2>(M, n, info);
+    glu_factor_step<PIV, 3>(M, n, info); glu_factor_step<PIV, 4>(M, n, info); glu_factor_step<PIV, 5>(M, n, info);
+    glu_factor_step<PIV, 6>(M, n, info); glu_factor_step<PIV, 7>(M, n, info);
     return info;
 }
 
-// Solve M X = B for NC right-hand sides at once: b[c] of lane r = B[r][c] (row r of B); on return x[c] of lane i = X[i][c].
-template <int NC> __device__ inline void glu_solve(const GLU &M, int n, double (&b)[NC])
+// Solve M X = B for NC right-hand sides at once: b[c] of lane r = B[r][c] (row r of B); on return b[c] of lane i = X[i][c].
+template <bool PIV, int K, int NC> __device__ __forceinline__ void glu_fwd_step(const GLU &M, int n, double (&b)[NC])
 {
+    if (K >= n) return;
     const int r = grp_lane();
+    const int p = PIV ? (int)((M.piv >> (3 * K)) & 7u) : K;
+    const bool later = PIV ? (M.ord > K && r < n) : (r > K && r < n);     // rows that come later in the pivot order lose l * (pivot row's b)
 #pragma unroll
-    for (int k = 0; k < GS; ++k) {           // forward: rows that come later in the pivot order lose l * (pivot row's b)
-        if (k >= n) break;
-        const int p = (M.piv >> (3 * k)) & 7;
-        const bool later = M.ord > k && r < n;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double bp = gsh(b[c], p);
-            if (later) b[c] -= M.a[k] * bp;
-        }
+    for (int c = 0; c < NC; ++c) {
+        const double bp = PIV ? gsh(b[c], p) : gbc<K>(b[c]);
+        if (later) b[c] -= M.a[K] * bp;
     }
+}
+template <bool PIV, int K, int NC> __device__ __forceinline__ void glu_bwd_step(const GLU &M, int n, double (&b)[NC], double (&x)[NC])
+{
+    if (K >= n) return;
+    const int r = grp_lane();
+    const int p = PIV ? (int)((M.piv >> (3 * K)) & 7u) : K;
+    const bool earlier = PIV ? M.ord < K : r < K;          // component K is finished in the step-K pivot lane, then leaves the earlier rows
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double mine = b[c] * M.a[K];                  // (meaningful in the pivot lane only: a[K] = 1 / U_KK there)
+        const double xk = PIV ? gsh(mine, p) : gbc<K>(mine);
+        if (earlier) b[c] -= M.a[K] * xk;
+        if (r == K) x[c] = xk;
+    }
+}
+template <bool PIV, int NC> __device__ __forceinline__ void glu_solve(const GLU &M, int n, double (&b)[NC])
+{
+    glu_fwd_step<PIV, 0, NC>(M, n, b); glu_fwd_step<PIV, 1, NC>(M, n, b); glu_fwd_step<PIV, 2, NC>(M, n, b); glu_fwd_step<PIV, 3, NC>(M, n, b);
+    glu_fwd_step<PIV, 4, NC>(M, n, b); glu_fwd_step<PIV, 5, NC>(M, n, b); glu_fwd_step<PIV, 6, NC>(M, n, b); glu_fwd_step<PIV, 7, NC>(M, n, b);
     double x[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) x[c] = 0.0;
-#pragma unroll
-    for (int k = GS - 1; k >= 0; --k) {      // backward: component k is finished in the step-k pivot lane, then leaves the earlier rows
-        if (k >= n) continue;
-        const int p = (M.piv >> (3 * k)) & 7;
-        const bool earlier = M.ord < k;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double xk = gsh(b[c] / M.a[k], p);
-            if (earlier) b[c] -= M.a[k] * xk;
-            if (r == k) x[c] = xk;
-        }
-    }
+    glu_bwd_step<PIV, 7, NC>(M, n, b, x); glu_bwd_step<PIV, 6, NC>(M, n, b, x); glu_bwd_step<PIV, 5, NC>(M, n, b, x); glu_bwd_step<PIV, 4, NC>(M, n, b, x);
+    glu_bwd_step<PIV, 3, NC>(M, n, b, x); glu_bwd_step<PIV, 2, NC>(M, n, b, x); glu_bwd_step<PIV, 1, NC>(M, n, b, x); glu_bwd_step<PIV, 0, NC>(M, n, b, x);
 #pragma unroll
     for (int c = 0; c < NC; ++c) b[c] = x[c];
 }
-__device__ inline double glu_solve1(const GLU &M, int n, double b)
+template <bool PIV> __device__ __forceinline__ double glu_solve1(const GLU &M, int n, double b)
 {
     double v[1] = {b};
-    glu_solve<1>(M, n, v);
+    glu_solve<PIV, 1>(M, n, v);
     return v[0];
 }
 
 // y_r = sum_{j < n} m[j] x_j  (row r of a matrix times a vector whose element j lives in lane j)
-__device__ inline double gmatvec(const double (&m)[GS], double x, int n)
+template <int J> __device__ __forceinline__ void gmatvec_step(const double (&m)[GS], double x, int n, double &acc)
+{
+    if (J < n) acc += m[J] * gbc<J>(x);
+}
+__device__ __forceinline__ double gmatvec(const double (&m)[GS], double x, int n)
 {
     double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < GS; ++j) {
-        if (j >= n) break;
-        acc += m[j] * gsh(x, j);
-    }
+    gmatvec_step<0>(m, x, n, acc); gmatvec_step<1>(m, x, n, acc); gmatvec_step<2>(m, x, n, acc); gmatvec_step<3>(m, x, n, acc);
+    gmatvec_step<4>(m, x, n, acc); gmatvec_step<5>(m, x, n, acc); gmatvec_step<6>(m, x, n, acc); gmatvec_step<7>(m, x, n, acc);
     return acc;
 }
 // C = A B with A row-distributed (lane r: row r, k columns) and B row-distributed (lane l: row l): c[j] = sum_l a[l] B[l][j]
-__device__ inline void gmatmul(const double (&a)[GS], const double (&b)[GS], int k, int ncol, double (&c)[GS])
+template <int L> __device__ __forceinline__ void gmatmul_step(const double (&a)[GS], const double (&b)[GS], int k, int ncol, double (&c)[GS])
+{
+    if (L >= k) return;
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+        if (j >= ncol) break;
+        c[j] += a[L] * gbc<L>(b[j]);
+    }
+}
+__device__ __forceinline__ void gmatmul(const double (&a)[GS], const double (&b)[GS], int k, int ncol, double (&c)[GS])
 {
 #pragma unroll
     for (int j = 0; j < GS; ++j) c[j] = 0.0;
-#pragma unroll
-    for (int l = 0; l < GS; ++l) {
-        if (l >= k) break;
-#pragma unroll
-        for (int j = 0; j < GS; ++j) {
-            if (j >= ncol) break;
-            c[j] += a[l] * gsh(b[j], l);
-        }
-    }
+    gmatmul_step<0>(a, b, k, ncol, c); gmatmul_step<1>(a, b, k, ncol, c); gmatmul_step<2>(a, b, k, ncol, c); gmatmul_step<3>(a, b, k, ncol, c);
+    gmatmul_step<4>(a, b, k, ncol, c); gmatmul_step<5>(a, b, k, ncol, c); gmatmul_step<6>(a, b, k, ncol, c); gmatmul_step<7>(a, b, k, ncol, c);
 }
 
 struct GSys {
@@ -164,7 +227,7 @@ struct GSys {
     double R[GS], B12[GS], B21[GS];                           // R (ni x ni), A Q^-1 G^T (ne x ni), G Q^-1 A^T (ni x ne)
 };
 
-__device__ inline void load_rows(double (&dst)[GS], const double *base, int nrow, int ncol, int rs, int cs)
+__device__ __forceinline__ void load_rows(double (&dst)[GS], const double *base, int nrow, int ncol, int rs, int cs)
 {
     const int r = grp_lane();
 #pragma unroll
@@ -172,16 +235,16 @@ __device__ inline void load_rows(double (&dst)[GS], const double *base, int nrow
 }
 
 // batch.py:413-479
-__device__ inline int g_pre_factor(GSys &S)
+__device__ __forceinline__ int g_pre_factor(GSys &S)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne;
 #pragma unroll
     for (int j = 0; j < GS; ++j) S.Q.a[j] = S.Qr[j];
-    const int bad_q = glu_factor(S.Q, nz);                    // (no early return: the groups of a wavefront stay in step)
+    const int bad_q = glu_factor<false>(S.Q, nz);                    // (no early return: the groups of a wavefront stay in step)
     double XG[GS];                                            // Q^-1 G^T (nz x ni), row r
 #pragma unroll
     for (int j = 0; j < GS; ++j) XG[j] = S.GT[j];
-    glu_solve<GS>(S.Q, nz, XG);
+    glu_solve<false, GS>(S.Q, nz, XG);
     gmatmul(S.G, XG, nz, ni, S.R);                            // R = G Q^-1 G^T + F
 #pragma unroll
     for (int j = 0; j < GS; ++j) S.R[j] += S.F[j];
@@ -189,14 +252,14 @@ __device__ inline int g_pre_factor(GSys &S)
         double XA[GS], Tm[GS], t[GS];
 #pragma unroll
         for (int j = 0; j < GS; ++j) XA[j] = S.AT[j];
-        glu_solve<GS>(S.Q, nz, XA);                           // Q^-1 A^T (nz x ne)
+        glu_solve<false, GS>(S.Q, nz, XA);                           // Q^-1 A^T (nz x ne)
         gmatmul(S.A, XA, nz, ne, S.S11.a);                    // A Q^-1 A^T
         gmatmul(S.G, XA, nz, ne, S.B21);                      // G Q^-1 A^T
         gmatmul(S.A, XG, nz, ni, S.B12);                      // A Q^-1 G^T
-        glu_factor(S.S11, ne);
+        glu_factor<false>(S.S11, ne);
 #pragma unroll
         for (int j = 0; j < GS; ++j) Tm[j] = S.B12[j];
-        glu_solve<GS>(S.S11, ne, Tm);                         // (A Q^-1 A^T)^-1 A Q^-1 G^T (ne x ni)
+        glu_solve<false, GS>(S.S11, ne, Tm);                         // (A Q^-1 A^T)^-1 A Q^-1 G^T (ne x ni)
         gmatmul(S.B21, Tm, ne, ni, t);
 #pragma unroll
         for (int j = 0; j < GS; ++j) S.R[j] -= t[j];
@@ -205,54 +268,48 @@ __device__ inline int g_pre_factor(GSys &S)
 }
 
 // batch.py:485-520: T = R + diag(1/d)
-__device__ inline void g_factor_kkt(GSys &S, double d)
+__device__ __forceinline__ void g_factor_kkt(GSys &S, double d)
 {
     const int r = grp_lane();
     const double id = 1.0 / d;
 #pragma unroll
     for (int j = 0; j < GS; ++j) S.T.a[j] = S.R[j] + (j == r ? id : 0.0);
-    glu_factor(S.T, S.ni);
+    glu_factor<true>(S.T, S.ni);
 }
 
 // batch.py:380-410; vectors have element i in lane i; has_* = 0 means the vector is zero
-__device__ inline void g_solve_kkt(const GSys &S, double d, double rx, double rs, double rz, double ry, double &dx, double &ds,
+__device__ __forceinline__ void g_solve_kkt(const GSys &S, double d, double rx, double rs, double rz, double ry, double &dx, double &ds,
                                    double &dz, double &dy)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne, r = grp_lane();
-    const double t = glu_solve1(S.Q, nz, r < nz ? rx : 0.0);
+    const double t = glu_solve1<false>(S.Q, nz, r < nz ? rx : 0.0);
     double h1 = 0.0, h2 = 0.0;
-    {   // A t and G t share the broadcasts of t
-        double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < GS; ++j) {
-            if (j >= nz) break;
-            const double tj = gsh(t, j);
-            a1 += S.A[j] * tj; a2 += S.G[j] * tj;
-        }
+    {
+        const double a1 = gmatvec(S.A, t, nz), a2 = gmatvec(S.G, t, nz);
         h1 = r < ne ? a1 - ry : 0.0;
         h2 = r < ni ? a2 + rs / d - rz : 0.0;
     }
     double w1 = 0.0, w2;
     if (ne > 0) {
-        const double y1 = glu_solve1(S.S11, ne, h1);
+        const double y1 = glu_solve1<false>(S.S11, ne, h1);
         const double h2p = h2 - gmatvec(S.B21, y1, ne);
-        w2 = glu_solve1(S.T, ni, r < ni ? h2p : 0.0);
+        w2 = glu_solve1<true>(S.T, ni, r < ni ? h2p : 0.0);
         const double b12w = gmatvec(S.B12, w2, ni);          // (every lane takes part in the broadcasts, whatever it keeps)
-        w1 = glu_solve1(S.S11, ne, r < ne ? h1 - b12w : 0.0);
+        w1 = glu_solve1<false>(S.S11, ne, r < ne ? h1 - b12w : 0.0);
     } else {
-        w2 = glu_solve1(S.T, ni, h2);
+        w2 = glu_solve1<true>(S.T, ni, h2);
     }
     w1 = -w1; w2 = -w2;
     double g1 = -rx - gmatvec(S.GT, w2, ni);
     if (ne > 0) g1 -= gmatvec(S.AT, w1, ne);
-    dx = glu_solve1(S.Q, nz, r < nz ? g1 : 0.0);
+    dx = glu_solve1<false>(S.Q, nz, r < nz ? g1 : 0.0);
     dz = r < ni ? w2 : 0.0;
     ds = r < ni ? (-rs - w2) / d : 0.0;
     dy = r < ne ? w1 : 0.0;
 }
 
 // batch.py:234-237, per system: element i in lane i (lanes >= n neutral)
-__device__ inline double g_get_step(double v, double dv, bool on)
+__device__ __forceinline__ double g_get_step(double v, double dv, bool on)
 {
     const double a = on ? -v / dv : -INFINITY;
     const double amax = gmax(a);
@@ -260,7 +317,7 @@ __device__ inline double g_get_step(double v, double dv, bool on)
     return gmin(on ? (dv > 0.0 ? repl : -v / dv) : INFINITY);
 }
 
-__device__ inline void load_system(GSys &S, const double *Q, const double *G, const double *A, const double *F, size_t sys)
+__device__ __forceinline__ void load_system(GSys &S, const double *Q, const double *G, const double *A, const double *F, size_t sys)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne;
     load_rows(S.Qr, Q + sys * nz * nz, nz, nz, nz, 1);
@@ -279,8 +336,22 @@ __device__ inline void load_system(GSys &S, const double *Q, const double *G, co
     S.S11.ord = GS; S.S11.piv = 0u;
 }
 
+template <int K> __device__ __forceinline__ void spd_step(double (&a)[GS], int nz, int &ok)
+{
+    if (K >= nz) return;
+    const int r = grp_lane();
+    double pr[GS];
+#pragma unroll
+    for (int j = K; j < GS; ++j) pr[j] = gbc<K>(a[j]);
+    if (!(pr[K] > 0.0)) ok = 0;
+    if (r > K && r < nz) {
+        const double l = a[K] / pr[K];
+#pragma unroll
+        for (int j = K + 1; j < GS; ++j) a[j] -= l * pr[j];
+    }
+}
 // lcp.py:109-113 stand-in: the symmetric part of Q is positive definite iff unpivoted elimination meets positive pivots only
-__device__ inline int g_is_spd(const GSys &S, const double *Q, size_t sys)
+__device__ __forceinline__ int g_is_spd(const GSys &S, const double *Q, size_t sys)
 {
     const int nz = S.nz, r = grp_lane();
     double a[GS], qt[GS];
@@ -288,23 +359,15 @@ __device__ inline int g_is_spd(const GSys &S, const double *Q, size_t sys)
 #pragma unroll
     for (int j = 0; j < GS; ++j) a[j] = 0.5 * (S.Qr[j] + qt[j]);
     int ok = 1;
-#pragma unroll
-    for (int k = 0; k < GS; ++k) {
-        if (k >= nz) break;
-        double pr[GS];
-#pragma unroll
-        for (int j = k; j < GS; ++j) pr[j] = gsh(a[j], k);
-        if (!(pr[k] > 0.0)) ok = 0;
-        if (r > k && r < nz) {
-            const double l = a[k] / pr[k];
-#pragma unroll
-            for (int j = k + 1; j < GS; ++j) a[j] -= l * pr[j];
-        }
-    }
+    spd_step<0>(a, nz, ok); spd_step<1>(a, nz, ok); spd_step<2>(a, nz, ok); spd_step<3>(a, nz, ok);
+    spd_step<4>(a, nz, ok); spd_step<5>(a, nz, ok); spd_step<6>(a, nz, ok); spd_step<7>(a, nz, ok);
     return ok;
 }
 
-__global__ void __launch_bounds__(64)
+#if !defined(DSS_GRP_WAVES)
+#define DSS_GRP_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, DSS_GRP_WAVES)
 lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G, const double *h, const double *A, const double *b,
                                const double *F, int B, int nz, int ni, int ne, double eps, int not_improved_lim, int max_iter,
                                int check_spd, double *zhat, double *lam, double *slack, double *nu, int *iters, int *status)
@@ -414,16 +477,19 @@ lcp_dense_group_backward_kernel(const double *Q, const double *G, const double *
     g_solve_kkt(S, d, g, 0.0, 0.0, 0.0, dx, dsv, dlam, dnu);
     const bool w = real && rc == 0;
     // outer products: row r of each gradient needs the whole of z / dx / lam
-#pragma unroll
-    for (int j = 0; j < GS; ++j) {
-        const double zj = gsh(zl, j), dxj = gsh(dx, j), lj = gsh(on ? lv : 0.0, j);
-        if (w && j < nz) {
-            if (r < nz) dQ[sys * nz * nz + (size_t)r * nz + j] = 0.5 * (dx * zj + zl * dxj);
-            if (on) dG[sys * ni * nz + (size_t)r * nz + j] = dlam * zj + lv * dxj;
-            if (ne > 0 && r < ne) dA[sys * ne * nz + (size_t)r * nz + j] = dnu * zj + nv * dxj;
-        }
-        if (w && j < ni && on) dF[sys * ni * ni + (size_t)r * ni + j] = dlam * lj;
+    const double lz = on ? lv : 0.0;
+#define DSS_GRP_OUTER(J)                                                                                                 \
+    {                                                                                                                    \
+        const double zj = gbc<J>(zl), dxj = gbc<J>(dx), lj = gbc<J>(lz);                                                 \
+        if (w && J < nz) {                                                                                               \
+            if (r < nz) dQ[sys * nz * nz + (size_t)r * nz + J] = 0.5 * (dx * zj + zl * dxj);                              \
+            if (on) dG[sys * ni * nz + (size_t)r * nz + J] = dlam * zj + lv * dxj;                                        \
+            if (ne > 0 && r < ne) dA[sys * ne * nz + (size_t)r * nz + J] = dnu * zj + nv * dxj;                           \
+        }                                                                                                                \
+        if (w && J < ni && on) dF[sys * ni * ni + (size_t)r * ni + J] = dlam * lj;                                        \
     }
+    DSS_GRP_OUTER(0) DSS_GRP_OUTER(1) DSS_GRP_OUTER(2) DSS_GRP_OUTER(3) DSS_GRP_OUTER(4) DSS_GRP_OUTER(5) DSS_GRP_OUTER(6) DSS_GRP_OUTER(7)
+#undef DSS_GRP_OUTER
     if (w) {
         if (r < nz) dp[sys * nz + r] = dx;
         if (on) dh[sys * ni + r] = -dlam;
