@@ -86,6 +86,27 @@ def test_benchmark_stack_scenes_in_the_full_batch_follow_the_reference():
     assert sum(flick.values()) <= 0.25 * 11 * len(gs), flick
 
 
+def test_benchmark_stack_scene_over_the_full_200_step_horizon():
+    """BASELINE's horizon for configs[2] is 200 steps; the reference was run that long on scene 1 of the benchmark batch
+    (oracle/gen/gen_bench_golden.py stack200 -> tests/golden/bench_stack_s1_200steps.npz: 71-73 contacts, the stack settles and
+    rests).  Stepped here as scene 1 of a 64-scene batch: every one of the 200 sub-steps' poses to 1e-9 and velocities to 1e-8
+    (measured 7e-14 / 9e-13), ordered pair lists exact with the corner-tie allowance of _check_tape_against_golden, and the
+    gradient of sum |pos_T|^2 w.r.t. the seven boxes' dimensions.  The stack is at rest, so those gradients are 1e-8 of a loss of
+    115: they are held to 1e-5 of the largest component with the absolute floor of 1e-10 the ten-step test uses (measured 6e-12)."""
+    gs, E = _stack_engine(64, 8, max_sub=208)
+    g = R.load_rollout("bench_stack_s1_200steps")
+    assert np.array_equal(g["pose0"], gs[1]["pose0"]) and np.array_equal(g["verts_3"], gs[1]["verts_3"])
+    for _ in range(200):
+        E.step()
+    assert int(E.get("overflow").max()) == 0 and np.isfinite(E.get("pose")).all()
+    flick = _check_tape_against_golden(E, g, 1, 1e-9, 1e-8)
+    print("sub-steps of 200 with a pair's contact count off by one:", flick)
+    assert flick <= 50
+    R.sweep(E)
+    got = np.concatenate(R.param_grads(E, g, 1)); want = np.concatenate([g["grad_%d" % i] for i in range(7)])
+    assert np.isfinite(got).all() and np.abs(got - want).max() < max(1e-5 * np.abs(want).max(), 1e-10), np.abs(got - want).max()
+
+
 def test_benchmark_stack_scenes_with_the_references_coin_flips_imposed():
     """Scenes 0..7 of the benchmark batch, ten steps, taking the reference's side of every `stable_mask` coin flip while stepping
     (rollout_helpers.impose_reference_normals: flag and normal of the contacts between two outer steps): the trajectory then
