@@ -56,13 +56,17 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
 #endif
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;     // quad_perm [1,0,3,2], [2,3,0,1]; row_half_mirror
 
-// broadcast of lane J of every group of eight, J a compile-time constant: within J's quad by quad_perm, to the other quad through
-// the half mirror (2 DPP moves + a select per 32-bit half)
+// broadcast of lane J of every group of eight, J a compile-time constant.  gfx90a+ moves 64 bits per DPP instruction with the
+// row_newbcast controls (lane N of every row of 16 to the whole row); a row holds two groups, told apart by the bank mask
+// (banks 0-1 = lanes 0-7, banks 2-3 = lanes 8-15): two instructions per double.
 template <int J> __device__ __forceinline__ double gbc(double x)
 {
-    const double inq = dpp_mov<(J & 3) * 0x55>(x);          // every lane: element (J & 3) of its own quad
-    const double oth = dpp_mov<DPP_HALF_MIRROR>(inq);       // ... of the other quad of its group
-    return ((threadIdx.x >> 2) & 1) == (J >> 2) ? inq : oth;
+#if defined(DSS_EMU)
+    return __shfl(x, (threadIdx.x & (WAVE - GS)) | J, WAVE);
+#else
+    const double lo = __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0x3, false);          // lanes 8-15 of the row keep x for now
+    return __builtin_amdgcn_update_dpp(lo, x, 0x150 + 8 + J, 0xf, 0xc, false);
+#endif
 }
 __device__ __forceinline__ double gsum(double v)
 {
@@ -224,6 +228,7 @@ struct GSys {
     int nz, ni, ne;
     double G[GS], GT[GS], A[GS], AT[GS], F[GS], Qr[GS];     // rows r of G (ni x nz), G^T (nz x ni), A (ne x nz), A^T (nz x ne), F (ni x ni), Q
     GLU Q, S11, T;                                            // LU(Q), LU(A Q^-1 A^T), LU(T) with T = R + diag(1/d)
+    double Qi[GS], Si[GS];                                    // INV only: rows of Q^-1 and of (A Q^-1 A^T)^-1
     double R[GS], B12[GS], B21[GS];                           // R (ni x ni), A Q^-1 G^T (ne x ni), G Q^-1 A^T (ni x ne)
 };
 
@@ -234,8 +239,12 @@ __device__ __forceinline__ void load_rows(double (&dst)[GS], const double *base,
     for (int j = 0; j < GS; ++j) dst[j] = (r < nrow && j < ncol) ? base[(size_t)r * rs + (size_t)j * cs] : 0.0;
 }
 
-// batch.py:413-479
-__device__ __forceinline__ int g_pre_factor(GSys &S)
+// batch.py:413-479.  INV (the forward kernel): Q and A Q^-1 A^T are symmetric positive definite and fixed over the iterations, so
+// their inverses are formed once (the LU solve of the identity) and every later solve with them is one matrix-vector product --
+// eight independent broadcasts instead of a chain of sixteen dependent ones.  What the iterations lose in the last digits of a
+// Newton direction they regain at the next residual, which is evaluated from the data; the adjoint (one solve, nothing to
+// correct it afterwards) keeps the LU solves.
+template <bool INV> __device__ __forceinline__ int g_pre_factor(GSys &S)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne;
 #pragma unroll
@@ -264,10 +273,19 @@ __device__ __forceinline__ int g_pre_factor(GSys &S)
 #pragma unroll
         for (int j = 0; j < GS; ++j) S.R[j] -= t[j];
     }
+    if (INV) {
+        const int r = grp_lane();
+#pragma unroll
+        for (int j = 0; j < GS; ++j) { S.Qi[j] = j == r ? 1.0 : 0.0; S.Si[j] = j == r ? 1.0 : 0.0; }
+        glu_solve<false, GS>(S.Q, nz, S.Qi);
+        if (ne > 0) glu_solve<false, GS>(S.S11, ne, S.Si);
+    }
     return bad_q ? DSS_LCP_Q_SINGULAR : 0;
 }
 
-// batch.py:485-520: T = R + diag(1/d)
+// batch.py:485-520: T = R + diag(1/d), factored with partial pivoting as the reference factors it; afterwards the rows are MOVED
+// into pivot order (lane k takes the row that was the pivot of step k: one ds_bpermute per register, not chained), which leaves a
+// natural-order LU of P T: every solve with it then runs on compile-time partners, its right-hand side permuted on the way in.
 __device__ __forceinline__ void g_factor_kkt(GSys &S, double d)
 {
     const int r = grp_lane();
@@ -275,14 +293,28 @@ __device__ __forceinline__ void g_factor_kkt(GSys &S, double d)
 #pragma unroll
     for (int j = 0; j < GS; ++j) S.T.a[j] = S.R[j] + (j == r ? id : 0.0);
     glu_factor<true>(S.T, S.ni);
+    const int src = r < S.ni ? (int)((S.T.piv >> (3 * r)) & 7u) : r;
+    S.T.ord = src;                                           // (from here on: the lane whose right-hand-side element this lane takes)
+#pragma unroll
+    for (int j = 0; j < GS; ++j) S.T.a[j] = gsh(S.T.a[j], src);
+}
+__device__ __forceinline__ double g_solve_T(const GSys &S, double b) { return glu_solve1<false>(S.T, S.ni, gsh(b, S.T.ord)); }
+template <bool INV> __device__ __forceinline__ double g_solve_Q(const GSys &S, double b)
+{
+    return INV ? gmatvec(S.Qi, b, S.nz) : glu_solve1<false>(S.Q, S.nz, b);
+}
+template <bool INV> __device__ __forceinline__ double g_solve_S11(const GSys &S, double b)
+{
+    return INV ? gmatvec(S.Si, b, S.ne) : glu_solve1<false>(S.S11, S.ne, b);
 }
 
 // batch.py:380-410; vectors have element i in lane i; has_* = 0 means the vector is zero
+template <bool INV>
 __device__ __forceinline__ void g_solve_kkt(const GSys &S, double d, double rx, double rs, double rz, double ry, double &dx, double &ds,
-                                   double &dz, double &dy)
+                                            double &dz, double &dy)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne, r = grp_lane();
-    const double t = glu_solve1<false>(S.Q, nz, r < nz ? rx : 0.0);
+    const double t = g_solve_Q<INV>(S, r < nz ? rx : 0.0);
     double h1 = 0.0, h2 = 0.0;
     {
         const double a1 = gmatvec(S.A, t, nz), a2 = gmatvec(S.G, t, nz);
@@ -291,18 +323,18 @@ __device__ __forceinline__ void g_solve_kkt(const GSys &S, double d, double rx, 
     }
     double w1 = 0.0, w2;
     if (ne > 0) {
-        const double y1 = glu_solve1<false>(S.S11, ne, h1);
+        const double y1 = g_solve_S11<INV>(S, h1);
         const double h2p = h2 - gmatvec(S.B21, y1, ne);
-        w2 = glu_solve1<true>(S.T, ni, r < ni ? h2p : 0.0);
+        w2 = g_solve_T(S, r < ni ? h2p : 0.0);
         const double b12w = gmatvec(S.B12, w2, ni);          // (every lane takes part in the broadcasts, whatever it keeps)
-        w1 = glu_solve1<false>(S.S11, ne, r < ne ? h1 - b12w : 0.0);
+        w1 = g_solve_S11<INV>(S, r < ne ? h1 - b12w : 0.0);
     } else {
-        w2 = glu_solve1<true>(S.T, ni, h2);
+        w2 = g_solve_T(S, h2);
     }
     w1 = -w1; w2 = -w2;
     double g1 = -rx - gmatvec(S.GT, w2, ni);
     if (ne > 0) g1 -= gmatvec(S.AT, w1, ne);
-    dx = glu_solve1<false>(S.Q, nz, r < nz ? g1 : 0.0);
+    dx = g_solve_Q<INV>(S, r < nz ? g1 : 0.0);
     dz = r < ni ? w2 : 0.0;
     ds = r < ni ? (-rs - w2) / d : 0.0;
     dy = r < ne ? w1 : 0.0;
@@ -384,13 +416,13 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
     int st = DSS_LCP_OK;
     if (check_spd && !g_is_spd(S, Q, sys)) st = DSS_LCP_NOT_SPD;
     {
-        const int rc = g_pre_factor(S);       // (every group goes through it: the shuffles need all lanes)
+        const int rc = g_pre_factor<true>(S);       // (every group goes through it: the shuffles need all lanes)
         if (!st) st = rc;
     }
     // initial point, batch.py:85-110
     double x, s, z, y, d = 1.0;
     g_factor_kkt(S, d);
-    g_solve_kkt(S, d, pv, 0.0, -hv, -bv, x, s, z, y);
+    g_solve_kkt<true>(S, d, pv, 0.0, -hv, -bv, x, s, z, y);
     {
         const bool on = r < ni;
         double m = gmin(on ? s : INFINITY);
@@ -399,7 +431,7 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
         if (m < 0 && on) z -= m - 1.0;
     }
     bool active = real && st == DSS_LCP_OK;
-    double best = 0.0;
+    double best = 0.0, bx = 0.0, bs = 0.0, bz = 0.0, by = 0.0;      // the best iterate so far stays in registers and is written once
     int have_best = 0, not_improved = 0, it_done = 0;
     for (int it = 0; it < max_iter; ++it) {
         if (__ballot(active) == 0ull) break;
@@ -420,9 +452,7 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
         if (active) {
             if (!have_best || resid < best) {
                 best = resid; have_best = 1; not_improved = 0;
-                if (r < nz) zhat[sys * nz + r] = x;
-                if (on) { lam[sys * ni + r] = z; slack[sys * ni + r] = s; }
-                if (ne > 0 && r < ne) nu[sys * ne + r] = y;
+                bx = x; bs = s; bz = z; by = y;
             } else {
                 ++not_improved;
             }
@@ -430,13 +460,13 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
         }
         // affine direction, batch.py:174-192
         double dxa, dsa, dza, dya, dxc, dsc, dzc, dyc;
-        g_solve_kkt(S, d, rx, on ? z : 0.0, rz, ry, dxa, dsa, dza, dya);
+        g_solve_kkt<true>(S, d, rx, on ? z : 0.0, rz, ry, dxa, dsa, dza, dya);
         double alpha = fmin(fmin(g_get_step(z, dza, on), g_get_step(s, dsa, on)), 1.0);
         const double t3 = gsum(on ? (s + alpha * dsa) * (z + alpha * dza) : 0.0);
         double sig = t3 / sz;
         sig = sig * sig * sig;
         const double rs2 = on ? (-mu * sig + dsa * dza) / s : 0.0;
-        g_solve_kkt(S, d, 0.0, rs2, 0.0, 0.0, dxc, dsc, dzc, dyc);
+        g_solve_kkt<true>(S, d, 0.0, rs2, 0.0, 0.0, dxc, dsc, dzc, dyc);
         dxa += dxc; dsa += dsc; dza += dzc; dya += dyc;
         alpha = fmin(0.999 * fmin(g_get_step(z, dza, on), g_get_step(s, dsa, on)), 1.0);
         if (active) {
@@ -449,6 +479,11 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
     if (real && r == 0) {
         if (st != DSS_LCP_OK) { status[sys] = st; iters[sys] = 0; }
         else { iters[sys] = it_done; status[sys] = (best > 1.0) ? DSS_LCP_INACCURATE : DSS_LCP_OK; }
+    }
+    if (real && st == DSS_LCP_OK && have_best) {
+        if (r < nz) zhat[sys * nz + r] = bx;
+        if (r < ni) { lam[sys * ni + r] = bz; slack[sys * ni + r] = bs; }
+        if (ne > 0 && r < ne) nu[sys * ne + r] = by;
     }
     if (real && st != DSS_LCP_OK && r < nz) zhat[sys * nz + r] = 0.0;
 }
@@ -466,7 +501,7 @@ lcp_dense_group_backward_kernel(const double *Q, const double *G, const double *
     GSys S;
     S.nz = nz; S.ni = ni; S.ne = ne;
     load_system(S, Q, G, A, F, sys);
-    const int rc = g_pre_factor(S);
+    const int rc = g_pre_factor<false>(S);
     const bool on = r < ni;
     const double lv = on ? lam[sys * ni + r] : 1.0, sv = on ? slack[sys * ni + r] : 1.0;
     const double d = on ? fmax(lv, 1e-8) / fmax(sv, 1e-8) : 1.0;
@@ -474,7 +509,7 @@ lcp_dense_group_backward_kernel(const double *Q, const double *G, const double *
     const double g = r < nz ? dl_dz[sys * nz + r] : 0.0, zl = r < nz ? zhat[sys * nz + r] : 0.0;
     const double nv = (ne > 0 && r < ne) ? nu[sys * ne + r] : 0.0;
     double dx, dsv, dlam, dnu;
-    g_solve_kkt(S, d, g, 0.0, 0.0, 0.0, dx, dsv, dlam, dnu);
+    g_solve_kkt<false>(S, d, g, 0.0, 0.0, 0.0, dx, dsv, dlam, dnu);
     const bool w = real && rc == 0;
     // outer products: row r of each gradient needs the whole of z / dx / lam
     const double lz = on ? lv : 0.0;
