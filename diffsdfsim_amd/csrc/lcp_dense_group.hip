@@ -309,22 +309,23 @@ template <bool INV> __device__ __forceinline__ double g_solve_S11(const GSys &S,
 }
 
 // batch.py:380-410; vectors have element i in lane i; has_* = 0 means the vector is zero
-template <bool INV>
+// RS_ONLY: rx = rz = ry = 0 (the corrector, batch.py:194-199): the products with those zeros are left out
+template <bool INV, bool RS_ONLY = false>
 __device__ __forceinline__ void g_solve_kkt(const GSys &S, double d, double rx, double rs, double rz, double ry, double &dx, double &ds,
                                             double &dz, double &dy)
 {
     const int nz = S.nz, ni = S.ni, ne = S.ne, r = grp_lane();
-    const double t = g_solve_Q<INV>(S, r < nz ? rx : 0.0);
-    double h1 = 0.0, h2 = 0.0;
-    {
-        const double a1 = gmatvec(S.A, t, nz), a2 = gmatvec(S.G, t, nz);
-        h1 = r < ne ? a1 - ry : 0.0;
+    double h1 = 0.0, h2 = r < ni ? rs / d : 0.0;
+    if (!RS_ONLY) {
+        const double t = g_solve_Q<INV>(S, r < nz ? rx : 0.0);
+        const double a2 = gmatvec(S.G, t, nz);
         h2 = r < ni ? a2 + rs / d - rz : 0.0;
+        if (ne > 0) { const double a1 = gmatvec(S.A, t, nz); h1 = r < ne ? a1 - ry : 0.0; }
     }
     double w1 = 0.0, w2;
     if (ne > 0) {
-        const double y1 = g_solve_S11<INV>(S, h1);
-        const double h2p = h2 - gmatvec(S.B21, y1, ne);
+        double h2p = h2;
+        if (!RS_ONLY) { const double y1 = g_solve_S11<INV>(S, h1); h2p -= gmatvec(S.B21, y1, ne); }
         w2 = g_solve_T(S, r < ni ? h2p : 0.0);
         const double b12w = gmatvec(S.B12, w2, ni);          // (every lane takes part in the broadcasts, whatever it keeps)
         w1 = g_solve_S11<INV>(S, r < ne ? h1 - b12w : 0.0);
@@ -332,7 +333,7 @@ __device__ __forceinline__ void g_solve_kkt(const GSys &S, double d, double rx, 
         w2 = g_solve_T(S, h2);
     }
     w1 = -w1; w2 = -w2;
-    double g1 = -rx - gmatvec(S.GT, w2, ni);
+    double g1 = (RS_ONLY ? 0.0 : -rx) - gmatvec(S.GT, w2, ni);
     if (ne > 0) g1 -= gmatvec(S.AT, w1, ne);
     dx = g_solve_Q<INV>(S, r < nz ? g1 : 0.0);
     dz = r < ni ? w2 : 0.0;
@@ -466,7 +467,7 @@ lcp_dense_group_forward_kernel(const double *Q, const double *p, const double *G
         double sig = t3 / sz;
         sig = sig * sig * sig;
         const double rs2 = on ? (-mu * sig + dsa * dza) / s : 0.0;
-        g_solve_kkt<true>(S, d, 0.0, rs2, 0.0, 0.0, dxc, dsc, dzc, dyc);
+        g_solve_kkt<true, true>(S, d, 0.0, rs2, 0.0, 0.0, dxc, dsc, dzc, dyc);
         dxa += dxc; dsa += dsc; dza += dzc; dya += dyc;
         alpha = fmin(0.999 * fmin(g_get_step(z, dza, on), g_get_step(s, dsa, on)), 1.0);
         if (active) {
