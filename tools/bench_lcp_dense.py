@@ -31,8 +31,9 @@ for (B, nz, nineq, neq) in SIZES:
     algo = 8.0 * B * (nz * nz + nz + nineq * nz + nineq + neq * nz + neq + nineq * nineq + nz + 2 * nineq + neq)
     n = nz + nineq + neq
     flops = B * iters * (2.0 / 3.0 * nineq ** 3 + 2.0 * nineq * nineq * nz + 2.0 / 3.0 * (nz + neq) ** 3 + 4.0 * n * n)
-    rows.append(dict(B=B, nz=nz, nineq=nineq, neq=neq, ms=ms, iters_mean=iters, algorithmic_bytes=algo,
+    rows.append(dict(kernel="lcp_dense_group_forward_kernel (8 lanes per system)" if max(nz, nineq, neq) <= 8 else "lcp_dense_forward_kernel (wavefront per system)",
+                     B=B, nz=nz, nineq=nineq, neq=neq, ms=ms, iters_mean=iters, algorithmic_bytes=algo,
                      GBps=algo / ms / 1e6, frac_of_8TBps=algo / ms / 1e6 / 8000.0, est_flops=flops,
                      est_TFLOPs=flops / ms / 1e9, flop_per_byte=flops / algo, machine_balance_flop_per_byte=78.6e12 / 8e12))
     print(rows[-1], file=sys.stderr, flush=True)
-print(json.dumps(dict(kernel="lcp_dense_forward_kernel", rows=rows), indent=1))
+print(json.dumps(dict(rows=rows), indent=1))
