@@ -178,10 +178,14 @@ struct Lds {
     const double *Ag;   // global equality rows [neq][nz]
 };
 
-// contacts per piece of a run (one lane sums the P C P^T terms of one piece, assemble_K): with many contacts longer pieces keep
-// the number of lanes that meet at an LDS address down (84 contacts: 4 per piece measured best, 0.704 / 0.672 / 0.722 ms per
-// launch for 8 / 4 / 2); with few contacts every lane's chain should be as short as possible (config 2: <= 8 contacts)
-__device__ inline int chunk_len(int nc) { return nc > 48 ? 4 : (nc > 24 ? 2 : 1); }
+// contacts per piece of a run (assemble_K: four lanes per piece, one per 3-row band; the gathers: one lane per piece).  With many
+// contacts longer pieces keep the number of lanes that meet at an LDS address down and the 4 x pieces tasks of the assembly within
+// one round of the wavefront (84 contacts in ~14 runs: 0.543 / 0.537 / 0.533 ms per launch for 4 / 6 / 8); with few contacts every
+// lane's chain should be as short as possible (config 2: <= 8 contacts)
+#if !defined(DSS_CHUNK_BIG)
+#define DSS_CHUNK_BIG 8
+#endif
+__device__ inline int chunk_len(int nc) { return nc > 48 ? DSS_CHUNK_BIG : (nc > 24 ? 2 : 1); }
 // sizes with a register-resident factor/solve: only H = Q + sum P C P^T is assembled in LDS, the equality rows join
 // in registers and the factored rows are parked in the (L2-resident) workspace between the two solves of an iteration
 __host__ __device__ inline bool reg_path(int n) { return n == 54 || n == 18; }
@@ -342,57 +346,59 @@ __device__ void assemble_K(Lds &L, const double *Mblk, const double *A, const in
             L.K[j * lda + nz + i] = v;
         }
     __syncthreads();
-    for (int base = 0; base < L.nchunks; base += WAVE) {
-        const int ci = base + lane;
-        const bool on = ci < L.nchunks;
+    // lane = (piece, band): the four 3-row bands of a piece's 12 x 12 block -- rows of body 1 (rotation, translation), of body 2
+    // (rotation, translation) -- go to four neighbouring lanes (they read the same C and p: LDS broadcasts), so the chain a
+    // lane walks is its piece's contacts once, not four times
+    const int ntask = 4 * L.nchunks;
+    for (int base = 0; base < ntask; base += WAVE) {
+        const int ti = base + lane, ci = ti >> 2, rp = ti & 3;
+        const bool on = ti < ntask;
         int c0 = 0, c1 = 0, b1 = 0, b2 = 0;
         if (on) {
             c0 = L.chunk[ci];
             c1 = ci + 1 < L.nchunks ? L.chunk[ci + 1] : nc;
             b1 = cbody[c0]; b2 = cbody[L.maxc + c0];
         }
-#pragma unroll 1
-        for (int rp = 0; rp < 4; ++rp) {      // band: rows of body 1 (rotation, translation), of body 2 (rotation, translation)
-            const bool rot = (rp & 1) == 0, first = rp < 2;
-            double sx1[3][3], sa[3][3], sx2[3][3];
+        const bool rot = (rp & 1) == 0, first = rp < 2;
+        double sx1[3][3], sa[3][3], sx2[3][3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { sx1[i][j] = 0.0; sa[i][j] = 0.0; sx2[i][j] = 0.0; }
-            for (int c = c0; c < c1; ++c) {
-                const double *Cp = L.cw + 9 * c, *pp = L.pbuf + 6 * c;
-                double C[9], p1[3], p2[3];
+            for (int j = 0; j < 3; ++j) { sx1[i][j] = 0.0; sa[i][j] = 0.0; sx2[i][j] = 0.0; }
+        for (int c = c0; c < c1; ++c) {
+            const double *Cp = L.cw + 9 * c, *pp = L.pbuf + 6 * c;
+            double C[9], p1[3], p2[3], pr[3];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) C[j] = Cp[j];
+            for (int j = 0; j < 9; ++j) C[j] = Cp[j];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { p1[j] = pp[j]; p2[j] = pp[3 + j]; }
-                const double *pr = first ? p1 : p2;
+            for (int j = 0; j < 3; ++j) { p1[j] = pp[j]; p2[j] = pp[3 + j]; pr[j] = first ? p1[j] : p2[j]; }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int ia = (i + 2) % 3, ib = (i + 1) % 3;
-                    double a[3], x1[3], x2[3];
+            for (int i = 0; i < 3; ++i) {
+                const int ia = (i + 2) % 3, ib = (i + 1) % 3;
+                double a[3], x1[3], x2[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)      // row i of X(p) C = (p x C[:, j])[i], or row i of C
-                        a[j] = rot ? pr[ib] * C[3 * ia + j] - pr[ia] * C[3 * ib + j] : C[3 * i + j];
-                    cross3(p1, a, x1);
-                    cross3(p2, a, x2);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { sx1[i][j] += x1[j]; sa[i][j] += a[j]; sx2[i][j] += x2[j]; }
+                for (int j = 0; j < 3; ++j) {    // row i of X(p) C = (p x C[:, j])[i], or row i of C
+                    const double xr = pr[ib] * C[3 * ia + j] - pr[ia] * C[3 * ib + j];
+                    a[j] = rot ? xr : C[3 * i + j];
                 }
+                cross3(p1, a, x1);
+                cross3(p2, a, x2);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { sx1[i][j] += x1[j]; sa[i][j] += a[j]; sx2[i][j] += x2[j]; }
             }
-            if (on) {
-                const int rb = first ? b1 : b2;
-                const double s1 = first ? 1.0 : -1.0, s2 = -s1;      // sign of the band against body 1's / body 2's columns
+        }
+        if (on) {
+            const int rb = first ? b1 : b2;
+            const double s1 = first ? 1.0 : -1.0, s2 = -s1;      // sign of the band against body 1's / body 2's columns
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    double *row = L.K + (6 * rb + (rot ? 0 : 3) + i) * lda;
+            for (int i = 0; i < 3; ++i) {
+                double *row = L.K + (6 * rb + (rot ? 0 : 3) + i) * lda;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        atomicAdd(row + 6 * b1 + j, s1 * sx1[i][j]);
-                        atomicAdd(row + 6 * b1 + 3 + j, s1 * sa[i][j]);
-                        atomicAdd(row + 6 * b2 + j, s2 * sx2[i][j]);
-                        atomicAdd(row + 6 * b2 + 3 + j, s2 * sa[i][j]);
-                    }
+                for (int j = 0; j < 3; ++j) {
+                    atomicAdd(row + 6 * b1 + j, s1 * sx1[i][j]);
+                    atomicAdd(row + 6 * b1 + 3 + j, s1 * sa[i][j]);
+                    atomicAdd(row + 6 * b2 + j, s2 * sx2[i][j]);
+                    atomicAdd(row + 6 * b2 + 3 + j, s2 * sa[i][j]);
                 }
             }
         }

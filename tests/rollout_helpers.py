@@ -47,22 +47,36 @@ def engine_kwargs(g, **over):
     return kw
 
 
-def check_contacts(E, s, body_ref, geom_ref, n_ref, tol=1e-6, coin_tol=None):
+def check_contacts(E, s, body_ref, geom_ref, n_ref, tol=1e-6, coin_tol=None, corner_ties=False):
     """Same ordered pair list; per ordered pair the same set of contact points (order inside a pair is
     implementation defined on both sides: Qhull vertex order vs ascending face id).  `coin_tol`: looser bound for the NORMAL
     (columns 0..2) -- a flat-on-flat contact takes it from either body on a rounding-noise comparison (contacts.py:198) and the
-    two bodies' normals may be up to the cluster angle (1e-2 rad) apart."""
+    two bodies' normals may be up to the cluster angle (1e-2 rad) apart.  `corner_ties`: a pair of boxes lying flat on each other may
+    differ from the reference by ONE contact (the corner of the face or its two neighbours on the edges become hull vertices,
+    decided by an argmin over three equal vertex distances, contacts.py:57-61: the reference's own count for such a pair flickers
+    from step to step, test_bench_scenes_gpu._check_tape_against_golden); its points are then not compared.  Returns the number
+    of such pairs."""
     nc = int(E.get("nc")[s])
     body = E.get("c_body")[s][:, :nc].T
     geom = E.get("c_geom")[s][:, :nc].T
-    assert nc == n_ref, (nc, n_ref)
-    assert [tuple(r) for r in body] == [tuple(r) for r in body_ref[:n_ref]], "ordered pair list differs"
+    ties = 0
+    if corner_ties:
+        dd = lambda L: [p for i, p in enumerate(L) if i == 0 or p != L[i - 1]]
+        assert dd([tuple(r) for r in body]) == dd([tuple(r) for r in body_ref[:n_ref]]), "ordered pair list differs"
+    else:
+        assert nc == n_ref, (nc, n_ref)
+        assert [tuple(r) for r in body] == [tuple(r) for r in body_ref[:n_ref]], "ordered pair list differs"
     for pair in sorted(set(map(tuple, body))):
         m = (body == pair).all(axis=1); mr = (body_ref[:n_ref] == pair).all(axis=1)
         a = geom[m]; b = geom_ref[:n_ref][mr]
+        if corner_ties and len(a) != len(b):
+            assert abs(len(a) - len(b)) == 1, (pair, len(a), len(b))
+            ties += 1
+            continue
         ia = np.lexsort(np.round(a[:, 3:6], 6).T[::-1]); ib = np.lexsort(np.round(b[:, 3:6], 6).T[::-1])
         d = np.abs(a[ia] - b[ib])
         assert d[:, 3:].max() < tol and d[:, :3].max() < (coin_tol or tol), (pair, d.max())
+    return ties
 
 
 def param_grads(E, g, s=0):
