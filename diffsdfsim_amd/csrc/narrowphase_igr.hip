@@ -690,7 +690,12 @@ int launch_igr_rounds(const DssWorld &W, hipStream_t stream)
     (void)hipMemsetAsync(W.igr_qn, 0, (size_t)2 * (DSS_IGR_ROUNDS + 2) * sizeof(int), stream);
     // one workgroup per item; with the caller's expectation (items of the previous detection) no more than that plus slack --
     // the kernel strides over the list, so any grid is correct (see igr_mlp.hip on what an idle workgroup costs)
-    int grid = W.igr_items_cap < 256 * 4 ? W.igr_items_cap : 256 * 4;
+#if !defined(DSS_IGR_ADV_GRID)
+#define DSS_IGR_ADV_GRID 256
+#endif
+    // (256 VGPRs, 45 KB of LDS: ONE workgroup per CU is resident, so more workgroups than CUs only queue up -- and every one of
+    //  them pays its launch with 360 KB of scratch even when its item has long finished)
+    int grid = W.igr_items_cap < DSS_IGR_ADV_GRID ? W.igr_items_cap : DSS_IGR_ADV_GRID;
     if (W.igr_hint) { int want = 2 * W.igr_hint[0] + 8; if (want < 64) want = 64; if (want < grid) grid = want; }
     for (int r = 0; r <= rounds; ++r) {
         if (r > 0) {

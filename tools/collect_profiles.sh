@@ -20,25 +20,7 @@ case "${1:-1}" in
 2)  kstats 2 40; kstats 5 200 --batch 128
     bench 5
     timeout -k 10 600 python3 tools/bench_lcp_dense.py > gpurun_out/r3_lcp_dense_hbm.json 2> gpurun_out/r3_lcp_dense_hbm.err; tail -c 600 gpurun_out/r3_lcp_dense_hbm.json
-    for ctr in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
-        tag=$(echo $ctr | cut -d' ' -f1)
-        rm -rf gpurun_out/dl_$tag
-        timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/dl_$tag -- python3 tools/bench_lcp_dense.py --quick > gpurun_out/dl_$tag.log 2>&1
-        python3 - "$tag" <<'PY'
-import collections, csv, glob, sys
-tag = sys.argv[1]
-fs = glob.glob("gpurun_out/dl_%s/*/*_counter_collection.csv" % tag)
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(fs[0])) if fs else []:
-    if "lcp_dense" in r["Kernel_Name"]:
-        acc[(r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open("gpurun_out/r3_lcp_dense_counters_%s.txt" % tag, "w") as f:
-    for k, cs in acc.items():
-        line = "%s grid %s  " % k + "  ".join("%s avg %.1f (n=%d)" % (c, sum(v) / len(v), len(v)) for c, v in cs.items())
-        print(line); f.write(line + "\n")
-PY
-        rm -rf gpurun_out/dl_$tag
-    done ;;
+    bash tools/pmc_lcp_dense.sh > gpurun_out/pmc_dense.log 2>&1; tail -c 300 gpurun_out/pmc_dense.log ;;
 3)  bash tools/pmc.sh 4 40 > gpurun_out/pmc4_run.log 2>&1; tail -1 gpurun_out/pmc4_run.log | cut -c1-200
     cp gpurun_out/r3_pmc_config4.json profiles/
     bench 4 ;;
