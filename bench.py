@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3, help="steps per sampled scene in the CPU baseline")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (capped by the affinity mask)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lockstep", action="store_true", help="one BatchEngine.step() per outer step for the whole batch (every scene waits for the slowest of each step) instead of BatchEngine.run(K)")
     ap.add_argument("--push", type=float, default=0.0, help="random lateral start velocity (0 = BASELINE config 3 as specified)")
     ap.add_argument("--spin-only", action="store_true", help="config 5: time only the 200-step spin of given inertias (round 2's line), "
                     "not the per-iteration rebuild latent -> 128^3 network grid -> marching cubes -> inertia")
@@ -424,8 +425,11 @@ def main():
 
     # warm-up: W steps forward + their backward (untimed)
     att = 0
-    for _ in range(Wm):
-        att += E.step()
+    if args.lockstep:
+        for _ in range(Wm):
+            att += E.step()
+    else:
+        att = E.run(Wm)
     loss_adjoint()
     E.adj["lo_slot"].zero_()
     E.backward_sweep(att)
@@ -468,8 +472,14 @@ def main():
 
     L = E.be.lib
 
-    def timed_step():
-        # BatchEngine.step with an event pair per attempt
+    def timed_steps(nsteps):
+        # BatchEngine.run(nsteps) (every scene goes through its own outer steps: DssWorld.steps_left) -- or, --lockstep,
+        # BatchEngine.step() -- with an event pair per attempt
+        if nsteps > 1:
+            if "steps_left" not in E.arr:
+                E.arr["steps_left"] = E.be.zeros((E.B,), np.int32)
+            E.arr["steps_left"][...] = nsteps
+            E.W.steps_left = E.be.ptr(E.arr["steps_left"])
         E._check(L.dss_step_begin(ctypes.byref(E.W), E.be.stream()), "dss_step_begin")
         n, k = E.B, 0
         while n > 0:
@@ -500,6 +510,7 @@ def main():
                         igr_pts.append((int(qn[2 * r]), int(qn[2 * r + 1])))
                         igr_est.append((int(hint_was[2 * r]), int(hint_was[2 * r + 1])) if hint_was is not None else (-1, -1))
             k += 1
+        E.W.steps_left = None
         return k
 
     if dist is not None:
@@ -507,8 +518,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     att = 0
-    for _ in range(K):
-        att += timed_step()
+    if args.lockstep:
+        for _ in range(K):
+            att += timed_steps(1)
+    else:
+        att = timed_steps(K)
     E.W.ev_lcp_start, E.W.ev_lcp_stop, E.W.ev_np_start, E.W.ev_np_stop = None, None, None, None
     E.W.igr_ev = None
     t_fwd = time.perf_counter()
@@ -606,7 +620,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": WORKLOAD[cfg] % (B, K),
                    "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
-                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "lcp_iters_mean": float(E.get("lcp_iters").mean()),
+                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "stepping": "lock-step (one step() per outer step)" if args.lockstep else "free-running (run(K): DssWorld.steps_left)", "lcp_iters_mean": float(E.get("lcp_iters").mean()),
                    "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
                    "forward_s": fwd_s, "backward_s": dt - fwd_s, "world_build_s": t_build,

@@ -209,6 +209,13 @@ __global__ void __launch_bounds__(64) decide_kernel(DssWorld W, NewContacts N)
             const double t = W.t[sc] + dt_try;                     // self.t += dt   (world.py:379)
             W.t[sc] = t;
             if (t < W.t_end[sc]) W.dt_try[sc] = W.t_end[sc] - t;   // step(): dt = end_t - self.t
+            else if (W.steps_left && W.steps_left[sc] > 1) {
+                // the scene's next World.step() begins here (begin_kernel's arithmetic), without waiting for the rest of the batch
+                W.steps_left[sc] -= 1;
+                W.t_end[sc] = t + W.dt;
+                W.dt_try[sc] = (t + W.dt) - t;
+                if (W.had_contacts) W.had_contacts[sc] = 0;
+            }
             else { W.active[sc] = 0; atomicAdd(W.n_active, -1); }
         }
     } else {

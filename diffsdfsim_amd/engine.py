@@ -277,6 +277,37 @@ class BatchEngine:
         self.attempts += k
         return k
 
+    def run(self, nsteps, max_attempts=1 << 20):
+        """`nsteps` outer steps of length dt for every scene, each scene going through its own `World.step()` calls without
+        waiting for the others (DssWorld.steps_left): a scene that halves its dt at a bounce holds nobody up, so the number of
+        attempt rounds is the largest per-scene total instead of the sum over steps of the per-step maximum.  State and tape
+        are those of `nsteps` calls of step(), bit for bit.  Returns the number of attempt rounds."""
+        if nsteps <= 0:
+            return 0
+        L, W = self.be.lib, self.W
+        if "steps_left" not in self.arr:
+            self.arr["steps_left"] = self.be.zeros((self.B,), np.int32)
+        self.arr["steps_left"][...] = int(nsteps)
+        W.step_mask = None
+        W.steps_left = self.be.ptr(self.arr["steps_left"])
+        try:
+            self._check(L.dss_step_begin(ctypes.byref(W), self.be.stream()), "dss_step_begin")
+            n, k = self.B, 0
+            while n > 0:
+                self._check(L.dss_step_attempt(ctypes.byref(W), ctypes.c_void_p(self.be.ptr(self.lcp_ws)),
+                                               ctypes.c_size_t(self.lcp_ws_bytes), self.be.stream()), "dss_step_attempt")
+                n = self.be.read_int(self.arr["n_active"])
+                if n & abi.N_ACTIVE_OVERFLOW:
+                    self._raise_overflow()
+                self._update_igr_hint(k == 0, n == 0)
+                k += 1
+                if k > max_attempts:
+                    raise RuntimeError("run did not finish within %d attempts" % max_attempts)
+        finally:
+            W.steps_left = None
+        self.attempts += k
+        return k
+
     def _raise_overflow(self):
         ov = self.get("overflow")
         s = int(np.nonzero(ov)[0][0])

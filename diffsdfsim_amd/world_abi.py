@@ -28,7 +28,7 @@ FIELDS = [
     ("fch_box", "pd"), ("vch_box", "pd"), ("mesh_fch_off", "pi"), ("mesh_vch_off", "pi"),
     ("Je", "pd"), ("b_eq", "pd"),
     ("t", "pd"), ("t_end", "pd"), ("dt_try", "pd"), ("last_dt", "pd"), ("dt_use", "pd"),
-    ("active", "pi"), ("step_mask", "pi"), ("had_contacts", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
+    ("active", "pi"), ("step_mask", "pi"), ("had_contacts", "pi"), ("steps_left", "pi"), ("toc", "pi"), ("nsub", "pi"), ("n_active", "pi"),
     ("nc", "pi"), ("c_body", "pi"), ("c_face", "pi"), ("c_abc", "pd"), ("c_geom", "pd"),
     ("n_nc", "pi"), ("n_body", "pi"), ("n_face", "pi"), ("n_abc", "pd"), ("n_geom", "pd"),
     ("pose0", "pd"), ("vel0", "pd"),

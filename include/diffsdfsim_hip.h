@@ -163,6 +163,11 @@ typedef struct DssWorld {
                               batch whose scenes are at different times, e.g. after a per-scene undo (optim_sphere.py:163-177) */
     int *had_contacts;  /* [B] any accepted sub-step of the current outer step ended with contacts (World.step's return value,
                            world.py:127-139) */
+    int *steps_left;    /* optional [B]: outer steps still to do INCLUDING the current one.  A scene that completes an outer step with
+                           steps_left > 1 starts its next one at once (what dss_step_begin does for it: t_end = t + dt, dt = t_end - t)
+                           instead of going inactive, so the scenes of a batch run through their `World.step()` calls independently --
+                           one that halves its dt at a bounce no longer holds the others for that outer step.  Per-scene results are
+                           those of stepping in lock-step, bit for bit (a scene never reads another's state).  NULL: lock-step */
     int *toc;        /* reference's `toc_contacts` non-empty */
     int *nsub;       /* accepted sub-steps so far (tape slot) */
     int *n_active;   /* [1] number of scenes still active after dss_step_decide | DSS_N_ACTIVE_OVERFLOW */

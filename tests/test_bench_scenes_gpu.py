@@ -263,3 +263,25 @@ def fresh_stacks_against_the_oracle(nS, T, backend=None):
         W.close()
     print("%d fresh stacks: worst pose difference to the CPU oracle %.2e; %d of %d (scene, sub-step, pair) contact sets differ by a corner / mid-edge tie" % (nS, worst, ties, npairs))
     assert ties <= 0.05 * npairs
+
+
+def test_free_running_batch_reproduces_lock_step_bit_for_bit():
+    """bench.py's timed region steps with BatchEngine.run(K) (DssWorld.steps_left: every scene goes through its own outer steps; one
+    that halves its dt at a bounce holds nobody up).  64 of the benchmark's sphere drops, 80 steps, both ways: state, times, tape and
+    -- after the reverse sweep -- every gradient array are identical bit for bit, in a fraction of the attempt rounds."""
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.engine import BatchEngine
+    out = []
+    for free in (False, True):
+        E = BatchEngine(scenes.sphere_drop(64, seed=R.BENCH_SEED), maxc=64, max_sub=400)
+        rounds = E.run(80) if free else sum(E.step() for _ in range(80))
+        st = {k: E.get(k).copy() for k in ("pose", "vel", "t", "nsub", "nc", "tp_pose", "tp_vel", "tp_dt", "tp_t", "tp_nc", "tp_lam", "tp_flags")}
+        R.sweep(E)
+        st.update({"adj_" + k: E.be.to_numpy(v).copy() for k, v in E.adj.items() if k.startswith("g_")})
+        out.append((rounds, st))
+    (r0, a), (r1, b) = out
+    assert int(a["nsub"].max()) > 80          # (some scene bounced: dt was halved)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    print("attempt rounds: lock-step %d, free-running %d (largest per-scene sub-step count %d)" % (r0, r1, int(a["nsub"].max())))
+    assert r1 < r0
