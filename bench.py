@@ -432,7 +432,7 @@ def main():
         att = E.run(Wm)
     loss_adjoint()
     E.adj["lo_slot"].zero_()
-    E.backward_sweep(att)
+    E.backward_sweep(int(E.arr["nsub"].max().item()))
 
     def gather_results():
         # "final trivial gather" of the shard results: final poses and the per-scene parameter gradients,
@@ -528,7 +528,10 @@ def main():
     t_fwd = time.perf_counter()
     loss_adjoint()
     E.adj["lo_slot"].copy_(lo)
-    E.backward_sweep(att)
+    # one reverse sweep iteration undoes one recorded sub-step per scene: as many as the longest tape segment of the timed region
+    # (rejected attempts left nothing on the tape)
+    n_sweeps = int((E.arr["nsub"] - lo).max().item())
+    E.backward_sweep(n_sweeps)
     gather_results()
     torch.cuda.synchronize()
     if dist is not None:
@@ -620,7 +623,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": WORKLOAD[cfg] % (B, K),
                    "scenes_per_gpu": B, "bodies": E.nb, "contacts_per_scene_mean": float(nc.mean()),
-                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "stepping": "lock-step (one step() per outer step)" if args.lockstep else "free-running (run(K): DssWorld.steps_left)", "lcp_iters_mean": float(E.get("lcp_iters").mean()),
+                   "contacts_per_scene_max": int(nc.max()), "attempts": att, "reverse_sweeps": n_sweeps, "stepping": "lock-step (one step() per outer step)" if args.lockstep else "free-running (run(K): DssWorld.steps_left)", "lcp_iters_mean": float(E.get("lcp_iters").mean()),
                    "substeps_mean": float((E.get("nsub") - E.be.to_numpy(lo)).mean()),
                    "scene_steps_per_s": world * B * K / dt, "capacity_overflow": overflow,
                    "forward_s": fwd_s, "backward_s": dt - fwd_s, "world_build_s": t_build,
