@@ -24,6 +24,9 @@
  * (lcp.py:109-113), 2 = LU of Q failed (batch.py:417-424).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -81,7 +84,11 @@ static int lu_factor(int n, double *a, int *piv)
         if (k1 == n) break;
         /* the panel's own rows, right of the panel: row i takes the updates of the panel rows above it */
         for (int i = k0 + 1; i < k1; ++i) lu_row_update(i - k0, n - k1, a + (size_t)i * n + k0, a + (size_t)i * n + k1, a + (size_t)k0 * n + k1, n);
-        /* trailing rows */
+        /* trailing rows: independent of each other (bit-identical in any order); shared among threads when the caller is not
+           itself one of a team working on different systems */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n - k1 >= 192 && !omp_in_parallel())
+#endif
         for (int i = k1; i < n; ++i) lu_row_update(kb, n - k1, a + (size_t)i * n + k0, a + (size_t)i * n + k1, a + (size_t)k0 * n + k1, n);
     }
     return info;
