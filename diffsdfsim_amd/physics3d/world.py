@@ -23,7 +23,7 @@ PARAMS = ("mass", "inertia", "restitution", "fric", "fext", "shape_prm")
 
 class _StepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm, verts=None, mask=None):
+    def forward(ctx, world, fixed_dt, pose, vel, mass, inertia, rest, fric, fext, prm, verts=None, mask=None, nsteps=1):
         # verts: the mesh table's vertices [NV,3] as a differentiable input (level-set meshes: their shape gradient flows
         # through the vertex positions); the engine already holds their values, only the adjoint is produced
         E = world.engine
@@ -38,7 +38,8 @@ class _StepFn(torch.autograd.Function):
             E.arr[name].copy_(t.detach().reshape(E.arr[name].shape))
             seen[name] = (t, t._version)
         nsub0 = E.arr["nsub"].clone()
-        att = E.step(mask=mask) if fixed_dt else E.step_once()
+        # nsteps > 1: that many outer steps per scene in ONE node, the scenes free-running (BatchEngine.run)
+        att = E.run(nsteps) if nsteps > 1 else (E.step(mask=mask) if fixed_dt else E.step_once())
         ctx.world, ctx.nsub0, ctx.att = world, nsub0, att
         ctx.nsub1 = E.arr["nsub"].clone()      # tape slots [nsub0, nsub1) belong to this node
         ctx.index = world._n_nodes
@@ -135,7 +136,7 @@ class _StepFn(torch.autograd.Function):
             adj["a_last_dt"][off] += al
         return (None, None, adj["a_pose"].clone(), adj["a_vel"].clone(), adj["g_mass"].clone(),
                 adj["g_inertia"].reshape(E.B, E.nb, 3, 3).clone(), adj["g_rest"].clone(), adj["g_fric"].clone(),
-                adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None, None)
+                adj["g_fext"].clone(), adj["g_prm"].clone(), adj["g_verts"].clone() if ctx.has_verts else None, None, None)
 
 
 class BatchWorld3D:
@@ -172,12 +173,14 @@ class BatchWorld3D:
 
     _UNDO_ARRAYS = ("t", "nc", "c_body", "c_face", "c_abc", "c_geom", "last_dt", "toc", "nsub")
 
-    def step(self, fixed_dt=True, mask=None, keep_undo=True):
+    def step(self, fixed_dt=True, mask=None, keep_undo=True, nsteps=1):
         """One outer step for every scene, or with `mask` ([B] booleans) for the selected scenes only (the others keep their
         state and time).  Returns [B] booleans: contacts present during the step (World.step's `had_contacts`, world.py:119-139;
         False for scenes the mask left out).  keep_undo=False skips the snapshot `undo_step` needs (nine device copies per step,
         the contact arrays among them) for callers that never undo."""
         E = self.engine
+        if nsteps > 1 and (mask is not None or not fixed_dt):
+            raise ValueError("run(nsteps) steps every scene with fixed_dt=True: no mask, no single step_dt")
         self._start_batch = (self.pose, self.vel, {k: E.arr[k].clone() for k in self._UNDO_ARRAYS}) if keep_undo else None
         if mask is not None:
             mask = np.asarray(mask.detach().cpu() if torch.is_tensor(mask) else mask).astype(np.int32)
@@ -197,7 +200,7 @@ class BatchWorld3D:
         outs = _StepFn.apply(self, fixed_dt, to("pose", self.pose), to("vel", self.vel), to("mass", P["mass"]),
                              to("inertia", P["inertia"]), to("restitution", P["restitution"]), to("fric", P["fric"]),
                              to("fext", P["fext"]), to("shape_prm", P["shape_prm"]),
-                             to("verts", P["verts"]) if P.get("verts") is not None else None, mask)
+                             to("verts", P["verts"]) if P.get("verts") is not None else None, mask, nsteps)
         self.pose, self.vel = outs[0], outs[1]
         # (record_substeps: the entries of the sub-steps inside this call -- poses / velocities [K, B, ...] with their graph, start
         # times [K, B], validity [K, B] -- and the start time of the last sub-step, whose entry is (self.pose, self.vel))
@@ -206,6 +209,17 @@ class BatchWorld3D:
         up["pose"], up["vel"] = (self.pose, self.pose._version), (self.vel, self.vel._version)
         had = self.engine.get("had_contacts") > 0
         return had if mask is None else had & (mask > 0)      # (the kernel clears the flag of stepped scenes only)
+
+    def run(self, nsteps):
+        """`nsteps` outer steps of length dt for every scene as ONE autograd node, the scenes going through their steps
+        independently of each other (BatchEngine.run / DssWorld.steps_left: a scene that halves its dt at a bounce holds nobody
+        up).  State, tape and gradients are those of `nsteps` calls of step(), bit for bit; what is given up is the per-step
+        Python control between them (masks, undo_step, per-step `had_contacts`).  With `record_substeps` the entries of ALL
+        accepted sub-steps of the call are in `self.substeps`."""
+        nsteps = int(nsteps)
+        if nsteps <= 0:
+            return
+        self.step(nsteps=nsteps, keep_undo=False)
 
     def undo_step(self, mask):
         """`World.undo_step` (lcp_physics/physics/world.py:106-116) for the scenes `mask` selects: time, poses, velocities

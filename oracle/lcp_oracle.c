@@ -54,6 +54,11 @@ SO_CLONES static void lu_row_update(int kb, int len, const double *l, double *ro
 /* In-place LU with partial pivoting (LAPACK getrf convention: piv[k] = row swapped with k).  Blocked for the cache (the
  * reference's LAPACK is): a panel of NB columns is eliminated, then every trailing row receives the panel's NB updates in one
  * pass.  Each element still sees the same subtractions in the same order as in the textbook elimination -- bit-identical. */
+/* threads one factorisation may share its trailing update among (0 / 1: none -- the default, and what every timing uses; the
+   tests that follow ONE scene over hundreds of steps switch it on to finish sooner) */
+static int g_lu_threads = 0;
+void lcp_oracle_set_lu_threads(int n) { g_lu_threads = n; }
+
 static int lu_factor(int n, double *a, int *piv)
 {
     enum { NB = 32 };
@@ -87,7 +92,7 @@ static int lu_factor(int n, double *a, int *piv)
         /* trailing rows: independent of each other (bit-identical in any order); shared among threads when the caller is not
            itself one of a team working on different systems */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) if (n - k1 >= 192 && !omp_in_parallel())
+#pragma omp parallel for schedule(static) num_threads(g_lu_threads > 1 ? g_lu_threads : 1) if (g_lu_threads > 1 && n - k1 >= 192 && !omp_in_parallel())
 #endif
         for (int i = k1; i < n; ++i) lu_row_update(kb, n - k1, a + (size_t)i * n + k0, a + (size_t)i * n + k1, a + (size_t)k0 * n + k1, n);
     }

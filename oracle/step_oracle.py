@@ -39,6 +39,12 @@ def lib():
     return _LIB
 
 
+def set_lu_threads(n):
+    """Threads ONE dense factorisation may share its trailing update among (bit-identical results).  Off by default and in
+    every timing; the tests that follow a single scene over hundreds of steps switch it on to finish sooner."""
+    lib().lcp_oracle_set_lu_threads(ctypes.c_int(int(n)))
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 

@@ -3,6 +3,8 @@ rollout goldens recorded from the imported reference.  This is what PINS the ora
 velocities and ordered contact-pair list, the contact points per pair as sets, and the reference's own `stable_mask`
 wherever its two Laplacians differ by more than rounding noise.  Run with scipy's Qhull behind the hull callback (what the
 reference calls) and with the C file's own hull (what the timing leg of bench.py uses)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -115,7 +117,11 @@ def test_step_oracle_over_the_full_200_step_horizon():
     spec, _gs = R.bench_spec("stack", 8, 8)
     g = R.load_rollout("bench_stack_s1_200steps")
     W = SO.World(spec, 1, hull="scipy")
-    W.step(200)
+    SO.set_lu_threads(min(8, os.cpu_count() or 1))     # (one scene, 2200 factorisations of 772 rows: shared among the cores)
+    try:
+        W.step(200)
+    finally:
+        SO.set_lu_threads(0)
     assert W.nsub == len(g["traj_t"]) == 200
     flick = 0
     for k in range(W.nsub):

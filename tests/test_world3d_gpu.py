@@ -86,6 +86,36 @@ def test_batchworld3d_parameter_gradients_flow():
     assert torch.isfinite(gr).all() and (gr != 0).any()
 
 
+def test_batchworld3d_run_is_one_node_with_the_gradients_of_the_step_loop():
+    """BatchWorld3D.run(n): n outer steps per scene in one autograd node with the scenes free-running (DssWorld.steps_left).  Final
+    state and d sum|pos|^2 / d radius are those of n calls of step() bit for bit; with record_substeps the entries of every
+    accepted sub-step come back with their graph (a loss on an intermediate entry gives the gradient of the step loop too)."""
+    from diffsdfsim_amd import scenes
+    from diffsdfsim_amd.physics3d import BatchWorld3D
+    out = []
+    for free in (False, True):
+        spec = scenes.sphere_drop(16, seed=3, floor_dims=(4.0, 1.0, 4.0))
+        prm = torch.tensor(spec["shape_prm"], dtype=torch.float64, requires_grad=True)
+        w = BatchWorld3D(spec, params=dict(shape_prm=prm), time_of_contact_diff=True, max_substeps=400)
+        w.record_substeps = True
+        if free:
+            w.run(40)
+            mid = w.substeps["pose"][1]                       # the state after every scene's 2nd accepted sub-step
+        else:
+            mid = None
+            for i in range(40):
+                w.step(keep_undo=False)
+                if i == 1:
+                    mid = w.pose                              # (no dt halving in the first two steps: sub-step 2 = step 2)
+        loss = (w.pose[:, :, 4:] ** 2).sum() + 0.5 * (mid[:, :, 4:] ** 2).sum()
+        loss.backward()
+        out.append((w.pose.detach().cpu().numpy().copy(), w.engine.get("nsub").copy(), prm.grad.detach().cpu().numpy().copy(), float(loss)))
+    (p0, n0, g0, l0), (p1, n1, g1, l1) = out
+    assert int(n0.max()) > 40                                 # somebody bounced
+    assert np.array_equal(p0, p1) and np.array_equal(n0, n1) and l0 == l1
+    assert np.abs(g0).max() > 0 and np.abs(g0 - g1).max() <= 1e-12 * np.abs(g0).max()
+
+
 def test_engine_plugin_solve_dynamics_matches_the_step():
     """B2: HipPdipmEngine.solve_dynamics(world, dt) (engines.py:31-83) returns the velocities the next accepted
     sub-step integrates with, without advancing the world."""
