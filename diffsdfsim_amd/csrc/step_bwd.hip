@@ -460,33 +460,46 @@ __global__ void __launch_bounds__(64) bwd_pre_kernel(DssWorld W_arg, DssAdjoint 
         }
         den = wave_sum(den);
         q = 0;
-        for (int c = lane; c < v.nc_n; c += 64, ++q) {
-            for (int r = 20; r < 53; ++r) cs[(size_t)r * MX + c] = 0.0;
-            if (!(den > 1e-5)) continue;
-            const double gq = q < 3 ? dDdh[q] : dD_dh(c);
-            if (gq == 0.0) continue;
-            const double wgt = -(gq / den) * dtbar_h;
-            double in[43], outg[44];
-            fill(c, in);
-            // one seed per pass: a time-of-contact event is rare (a handful of contacts per rollout), its 43 inputs with four
-            // tangents each were what set this kernel's register and scratch footprint for every launch
-#pragma unroll 1
-            for (int sd = 0; sd < 43; ++sd) {
-                typedef Dual<1> D;
-                D di[43];
-                for (int i = 0; i < 43; ++i) { di[i] = D(in[i]); di[i].d[0] = (i == sd) ? 1.0 : 0.0; }
-                outg[sd] = wgt * toc_D(di).d[0];
+        for (int c = lane; c < v.nc_n; c += 64) for (int r = 20; r < 53; ++r) cs[(size_t)r * MX + c] = 0.0;
+        __syncthreads();
+        // The gradient of D with respect to its 43 inputs, one dual-number pass per input.  A time-of-contact event is rare (a
+        // handful per rollout and scene) but its sweep iteration is the slowest scene's: with the 43 passes walked by the lane
+        // that owns the contact, a batch of free-running scenes -- where some scene meets an event in almost every iteration --
+        // spent 270 us per iteration here.  The passes of ONE contact go to 43 lanes instead (lane = seed); the contacts of an
+        // event (one to four) are taken one after the other.
+        for (int base = 0; base < v.nc_n; base += 64, ++q) {
+            const int c_own = base + lane;
+            double gq = 0.0;
+            if (c_own < v.nc_n && den > 1e-5) gq = q < 3 ? dDdh[q] : dD_dh(c_own);
+            unsigned long long todo = __ballot(gq != 0.0);
+            while (todo) {
+                const int bit = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int c = base + bit;
+                const double wgt = -(__shfl(gq, bit, 64) / den) * dtbar_h;
+                double in[43];
+                fill(c, in);
+                double og = 0.0;
+                if (lane < 43) {
+                    typedef Dual<1> D;
+                    D di[43];
+                    for (int i = 0; i < 43; ++i) { di[i] = D(in[i]); di[i].d[0] = (i == lane) ? 1.0 : 0.0; }
+                    og = wgt * toc_D(di).d[0];
+                }
+                // lane sd holds d/d in[sd]: geometry of the new contact (p1: 2-4, p2: 5-7, normal: 8-10), the two new velocities
+                // (11-16, 17-22), the two moved poses (23-29, 30-36), f/m of both bodies (37-39, 40-42), h (1)
+                const int sd = lane;
+                if (sd >= 2 && sd <= 4) a_geom[(size_t)(3 + sd - 2) * MX + c] += og;
+                else if (sd >= 5 && sd <= 7) a_geom[(size_t)(6 + sd - 5) * MX + c] += og;
+                else if (sd >= 8 && sd <= 10) a_geom[(size_t)(sd - 8) * MX + c] += og;
+                else if (sd >= 23 && sd <= 29) cs[(size_t)(20 + sd - 23) * MX + c] = og;
+                else if (sd >= 30 && sd <= 36) cs[(size_t)(27 + sd - 30) * MX + c] = og;
+                else if (sd >= 11 && sd <= 16) cs[(size_t)(34 + sd - 11) * MX + c] = og;
+                else if (sd >= 17 && sd <= 22) cs[(size_t)(40 + sd - 17) * MX + c] = og;
+                else if (sd >= 37 && sd <= 39) cs[(size_t)(46 + sd - 37) * MX + c] = og;
+                else if (sd >= 40 && sd <= 42) cs[(size_t)(49 + sd - 40) * MX + c] = og;
+                else if (sd == 1) cs[(size_t)52 * MX + c] = og;
             }
-            // geometry of the new contact
-            for (int i = 0; i < 3; ++i) {
-                a_geom[(size_t)(3 + i) * MX + c] += outg[2 + i];
-                a_geom[(size_t)(6 + i) * MX + c] += outg[5 + i];
-                a_geom[(size_t)i * MX + c] += outg[8 + i];
-            }
-            for (int i = 0; i < 7; ++i) { cs[(size_t)(20 + i) * MX + c] = outg[23 + i]; cs[(size_t)(27 + i) * MX + c] = outg[30 + i]; }
-            for (int i = 0; i < 6; ++i) { cs[(size_t)(34 + i) * MX + c] = outg[11 + i]; cs[(size_t)(40 + i) * MX + c] = outg[17 + i]; }
-            for (int i = 0; i < 3; ++i) { cs[(size_t)(46 + i) * MX + c] = outg[37 + i]; cs[(size_t)(49 + i) * MX + c] = outg[40 + i]; }
-            cs[(size_t)52 * MX + c] = outg[1];
         }
         __syncthreads();
         double hp = 0.0;
