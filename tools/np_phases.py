@@ -6,8 +6,13 @@ import numpy as np, torch
 from diffsdfsim_amd import scenes
 from diffsdfsim_amd.engine import BatchEngine, TorchBackend
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-spec = scenes.box_stack(B, nbox=7, seed=1)
-E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
+KIND = sys.argv[2] if len(sys.argv) > 2 else "stack"      # "sphere": configs[1]'s scenes after 150 steps (most spheres on the floor)
+if KIND == "sphere":
+    E = BatchEngine(scenes.sphere_drop(B, seed=1000), maxc=64, max_sub=900, backend=TorchBackend("cuda"))
+    E.run(150)
+else:
+    spec = scenes.box_stack(B, nbox=7, seed=1)
+    E = BatchEngine(spec, maxc=128, max_cand=1024, max_pc=48, strict_no_pen=False, backend=TorchBackend("cuda"))
 np_ = E.nb * (E.nb - 1)
 dbg = torch.zeros(B * np_ * 8, dtype=torch.int64, device="cuda")
 E.W.dbg_stamps = dbg.data_ptr()
