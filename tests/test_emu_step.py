@@ -74,16 +74,15 @@ def test_full_kernel_variants_agree_with_the_lean_ones(name, nsteps):
 
 def test_free_running_scenes_reproduce_lock_step_bit_for_bit():
     """BatchEngine.run(n) (DssWorld.steps_left: a scene that finishes an outer step starts its next one at once) against n calls of
-    step() on three sphere drops that reach the floor at different times: state, times, sub-step counts and the whole tape are
+    step() on two sphere drops that reach the floor at different times: state, times, sub-step counts and the whole tape are
     identical bit for bit, in fewer attempt rounds."""
     g = R.load_rollout("rollout_sphere")
     out = []
     for free in (False, True):
-        spec = R.spec_from_golden(g, 3)
+        spec = R.spec_from_golden(g, 2)
         mv = [b for b in range(spec["pose"].shape[1]) if b not in g["fixed"]][0]
         up = int(np.argmax(np.abs(spec["fext"][0, mv, 3:]))) + 4          # the axis gravity acts along
-        spec["pose"][1, mv, up] += 0.013
-        spec["pose"][2, mv, up] += 0.031
+        spec["pose"][1, mv, up] += 0.031
         E = BatchEngine(spec, backend=emu.EmuBackend(), max_sub=96, **R.engine_kwargs(g))
         rounds = E.run(24) if free else sum(E.step() for _ in range(24))
         out.append((rounds, {k: E.get(k).copy() for k in ("pose", "vel", "t", "nsub", "nc", "c_geom", "tp_pose", "tp_vel", "tp_dt", "tp_t", "tp_nc",
