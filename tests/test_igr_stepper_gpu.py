@@ -139,3 +139,30 @@ def test_system_identification_scene_gradients_match_reference_autograd():
     for name, t in (("grad_force", force), ("grad_mass", mass), ("grad_fric", fric)):
         got, want = t.grad.cpu().numpy(), g[name]
         assert np.abs(got - want).max() < 1e-5 * np.abs(want).max(), (name, got, want)
+
+
+def test_neural_body_scenes_free_running_reproduce_lock_step():
+    """bench.py --config 4 steps with BatchEngine.run(K) (DssWorld.steps_left): scenes with a neural SDF body go through their
+    outer steps independently while their network queries still share the launches of a round.  Four copies of the
+    `rollout_igr_small` scene with the neural body started at different heights, 12 outer steps both ways: poses, velocities,
+    times, sub-step counts, contacts and the tape are identical bit for bit (a query's result depends on the point alone)."""
+    from diffsdfsim_amd.engine import BatchEngine
+    g = R.load_rollout("rollout_igr_small")
+    out = []
+    for free in (False, True):
+        spec = H.spec_from_golden(g, 4)
+        mv = [b for b in range(spec["pose"].shape[1]) if b not in g["fixed"]][0]        # the neural body
+        f = spec["fext"][0, mv, 3:]
+        up = -f / np.linalg.norm(f)
+        for s, dz in enumerate((0.0, 0.011, 0.023, 0.037)):
+            spec["pose"][s, mv, 4:] += dz * up
+        E = BatchEngine(spec, **H.engine_kwargs(g, max_sub=256))
+        rounds = E.run(12) if free else sum(E.step() for _ in range(12))
+        assert int(E.get("overflow").max()) == 0
+        out.append((rounds, {k: E.get(k).copy() for k in ("pose", "vel", "t", "nsub", "nc", "c_geom", "tp_pose", "tp_vel", "tp_dt", "tp_nc", "tp_lam")}))
+    (r0, a), (r1, b) = out
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    print("attempt rounds: lock-step %d, free-running %d; sub-steps per scene %s" % (r0, r1, a["nsub"]))
+    assert len(set(a["nsub"])) > 1, "the scenes were meant to differ"
+    assert r1 <= r0
