@@ -976,6 +976,20 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
         pinned0 = neq == 6 && __ballot(!okl) == 0ull;
     }
 
+    // every contact between neighbours in the body order, or with the pinned body: H_oo is block tridiagonal (kkt_reg.h)
+    bool tri = false;
+    if constexpr (N > 12) {
+        bool okc = true;
+        for (int c = lane; c < nc; c += WAVE) {
+            const int b1 = L.cb[c], b2 = L.cb[maxc + c];
+            okc = okc && (b1 == 0 || b2 == 0 || b1 - b2 == 1 || b2 - b1 == 1);
+        }
+        tri = pinned0 && __ballot(!okc) == 0ull;
+        // (the decoupled form below is built for that shape only; a pinned scene whose contacts skip a body takes the general
+        //  elimination of the whole system like an unpinned one)
+        pinned0 = tri;
+    }
+
     double best = 0.0;
     int have_best = 0, not_improved = 0, it = 0;
     LSTAMP_INIT;
@@ -1085,7 +1099,7 @@ lcp_contact_forward_reg_kernel(const double *Mblk_, const double *pvec_, const d
                     ro = L.sol[lane + 6];
                     for (int i = 0; i < 6; ++i) ro -= L.K[(lane + 6) * L.lda + i] * L.sol[nz + i];
                 }
-                regk_factor_lead<(N > 0 ? N : 1), M>(R);
+                regk_factor_lead_tri<(N > 0 ? N : 1), M>(R);
                 const double xo = regk_solve_lead<(N > 0 ? N : 1), M>(R, ro);
                 if (lane < 6) L.dxa[lane] = L.sol[nz + lane];
                 if (lane < M) L.dxa[lane + 6] = xo;
