@@ -573,7 +573,10 @@ def main():
         if fl is None:
             r.update(achieved=None, frac=None, flops_per_launch=None, flops_note=pmc_note or "no fp64 instruction counters in the PMC file")
         else:
-            r.update(achieved=fl / t / 1e12, frac=fl / t / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=fl)
+            r.update(achieved=fl / t / 1e12, frac=fl / t / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=fl,
+                     flops_source="counter upper bound: SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 wave instructions x 64 lanes (masked-off lanes "
+                                  "count), averaged over the dispatches of a rocprofv3 --pmc pass of this library (profiles/, "
+                                  "lib_sha256), divided by the launch time measured live in this run")
             vb = pmc_sum(pmc, "valu_util_per_simd", frags[0])     # of the group's main kernel
             if vb is not None:
                 r["valu_util_per_simd"] = vb     # cycles in which a SIMD issues a VALU instruction / kernel cycles, chip average
