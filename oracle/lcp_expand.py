@@ -15,8 +15,9 @@ def friction_dirs(n, fd):
     return np.stack(dirs)
 
 
-def random_problem(seed, B, nb, maxc, fd=8, nc_lo=1, nc_hi=None, fixed_body0=True, ragged=True):
-    """Random scenes: SPD 6x6 mass blocks, body 0 pinned by 6 equality rows, random contacts."""
+def random_problem(seed, B, nb, maxc, fd=8, nc_lo=1, nc_hi=None, fixed_body0=True, ragged=True, chain=False):
+    """Random scenes: SPD 6x6 mass blocks, body 0 pinned by 6 equality rows, random contacts.  chain: every contact joins neighbours in
+    the body order or a body and body 0 -- a stack: the shape lcp_contact.hip's block-tridiagonal elimination is selected for."""
     r = np.random.default_rng(seed)
     ND = fd // 2
     NF = 3 * (1 + ND) + 8
@@ -39,6 +40,11 @@ def random_problem(seed, B, nb, maxc, fd=8, nc_lo=1, nc_hi=None, fixed_body0=Tru
         nc[s] = k
         for c in range(k):
             b1 = int(r.integers(0, nb)); b2 = int((b1 + 1 + r.integers(0, nb - 1)) % nb)
+            if chain:
+                if r.random() < 0.25:
+                    b1, b2 = (0, int(r.integers(1, nb))) if r.random() < 0.5 else (int(r.integers(1, nb)), 0)
+                else:
+                    lo = int(r.integers(1, nb - 1)); b1, b2 = (lo, lo + 1) if r.random() < 0.5 else (lo + 1, lo)
             n = r.standard_normal(3); n /= np.linalg.norm(n)
             D = np.concatenate([n[None], friction_dirs(n, fd)])
             cop[s, :3 * (1 + ND), c] = D.reshape(-1)

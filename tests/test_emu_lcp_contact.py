@@ -51,3 +51,15 @@ def test_no_contacts_is_plain_linear_solve():
         K = np.block([[Q, A.T], [A, np.zeros((6, 6))]])
         sol = np.linalg.solve(K, np.concatenate([-p, b]))
         assert rel(x[s], sol[:12]) < 1e-12 and it[s] == 0
+
+
+def test_block_tridiagonal_elimination_and_its_fallback_under_the_emulator():
+    """(tests/test_lcp_contact_gpu.py has the device version.)  Chain-structured contacts -> regk_factor_lead_tri; one contact that
+    skips a body -> the general elimination; both against the dense oracle."""
+    P = S.random_problem(seed=33, B=2, nb=8, maxc=24, fd=8, nc_lo=10, chain=True)
+    P["cbody"][1, :, 0] = (1, 3)
+    x, lam, slack, nu, it, st = emu.lcp_contact_forward(P, max_iter=10)
+    for s in range(2):
+        Q, p, G, h, A, b, F = S.expand_dense(P, s)
+        zo = O.forward(Q[None], p[None], G[None], h[None], A[None], b[None], F[None], max_iter=10)[0]
+        assert rel(x[s], zo[0]) < 1e-9, (s, rel(x[s], zo[0]))

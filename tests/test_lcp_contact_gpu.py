@@ -29,6 +29,29 @@ def run(P, max_iter=10):
     return d, out
 
 
+def test_block_tridiagonal_elimination_and_its_fallback_agree_with_the_dense_oracle():
+    """Eight bodies, body 0 pinned, every contact between neighbours in the body order or with body 0 (a stack): the kernel
+    eliminates H_oo as a block-tridiagonal matrix (kkt_reg.h: regk_factor_lead_tri).  One contact that skips a body (1 <-> 3) must
+    send the scene through the general elimination instead.  Both against the dense oracle at 1e-9, with 70-100 contacts (two
+    contacts per lane) and with 10-30."""
+    from oracle import lcp_oracle as O
+    for seed, maxc, lo in ((31, 128, 70), (32, 32, 10)):
+        P = S.random_problem(seed=seed, B=6, nb=8, maxc=maxc, fd=8, nc_lo=lo, chain=True)
+        cb = P["cbody"]
+        for s in range(6):
+            k = int(P["nc"][s])
+            assert all(a == 0 or b == 0 or abs(int(a) - int(b)) == 1 for a, b in cb[s][:, :k].T)
+        cb[4, :, 0] = (1, 3)          # scenes 4 and 5: no longer a chain
+        cb[5, :, 1] = (6, 2)
+        d, (x, lam, slack, nu, it, st) = run(P)
+        x, it = x.cpu().numpy(), it.cpu().numpy()
+        for s in range(6):
+            Q, p, G, h, A, b, F = S.expand_dense(P, s)
+            zo, lo_, so, nuo, ito, sto = O.forward(Q[None], p[None], G[None], h[None], A[None], b[None], F[None], max_iter=10)
+            assert abs(int(ito[0]) - int(it[s])) <= 1
+            assert rel(x[s], zo[0]) < 1e-9, (seed, s, rel(x[s], zo[0]))
+
+
 @pytest.mark.parametrize("cfg", [dict(seed=11, B=6, nb=2, maxc=8, fd=8), dict(seed=12, B=4, nb=8, maxc=32, fd=8),
                                  dict(seed=13, B=3, nb=3, maxc=8, fd=4), dict(seed=14, B=2, nb=4, maxc=96, fd=8, nc_lo=70),
                                  dict(seed=15, B=5, nb=2, maxc=8, fd=8), dict(seed=16, B=3, nb=8, maxc=24, fd=8, nc_lo=10),
